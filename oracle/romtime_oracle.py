@@ -1,0 +1,260 @@
+"""CPU oracle for the romtime POD / (M)DEIM / reduced-solve hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``romtime_amd/`` may import this
+module; only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline``
+leg of ``bench.py`` do, and there only as the checker / the timed CPU baseline.
+
+Every function restates, with the same NumPy/SciPy library calls, one function
+of the reference (KikeM/romtime @ v0, paths relative to ``/root/reference``).
+The arithmetic that is *not* in the reference tree (LAPACK ``dgesvd``/``dgesv``,
+BLAS, SciPy ``csr_matvecs`` and ``gmres``) is reached through the NumPy/SciPy of
+this image (numpy 2.2 / scipy 1.15; the reference pins numpy 1.20.1 /
+scipy 1.6.3 / openblas 0.3.12, ``environment.yml:77,107,204``).
+
+Parity pin: ``tests/golden/*.npz`` were produced by ``tests/golden/make_golden.py``
+by running the reference's own source (``/root/reference/src/romtime``) in the
+build container; ``tests/test_oracle_golden.py`` checks every function below
+against them.
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.linalg import svd
+from scipy.sparse import csr_matrix
+from scipy.sparse.linalg import gmres
+
+DROP_TOLERANCE = 1e-7  # src/romtime/rom/pod.py:4
+GMRES_OPTIONS = dict(atol=1e-10, rtol=1e-10, maxiter=int(1e6))  # rom/rom.py:36 (tol -> rtol in SciPy >= 1.14)
+ZERO_TOLERANCE = 1e-15  # src/romtime/utils.py:163
+
+
+# ---------------------------------------------------------------------------
+# a1  POD  -- src/romtime/rom/pod.py:7-62
+# ---------------------------------------------------------------------------
+def orth(snapshots, num=None, tol=None, normalize=True, return_VT=False):
+    """Thin-SVD POD with the reference's truncation precedence (pod.py:7-62)."""
+    if isinstance(snapshots, list):  # pod.py:27-28
+        raise ValueError("You should use an array, not a list.")
+    if normalize == True:  # noqa: E712  pod.py:31-33
+        l2_norms = np.linalg.norm(snapshots, axis=0)
+        _snapshots = np.divide(snapshots, l2_norms)
+    else:
+        _snapshots = snapshots
+    u, s, vt = svd(_snapshots, full_matrices=False, lapack_driver="gesvd")  # pod.py:38
+    eigenvalues = np.power(s, 2)  # pod.py:41-43
+    total = np.sum(eigenvalues)
+    energy = np.cumsum(eigenvalues) / total
+    if tol:  # pod.py:46-49
+        mask = energy < tol
+        Q = u[:, mask]
+        VT = vt[mask, :]
+    elif num:  # pod.py:51-53
+        Q = u[:, :num]
+        VT = vt[:num, :]
+    else:  # pod.py:55-57
+        Q = u[:, s > DROP_TOLERANCE]
+        VT = vt[s > DROP_TOLERANCE, :]
+    if return_VT:
+        return Q, s, energy, VT
+    return Q, s, energy
+
+
+# ---------------------------------------------------------------------------
+# a3  DEIM greedy  -- src/romtime/deim/deim.py:517-561
+# ---------------------------------------------------------------------------
+def build_interpolation_mesh(Vf):
+    """Reference form: dense one-hot P, dgemm against it (deim.py:517-561)."""
+    Nh = Vf.shape[0]
+    U = Vf[:, 0]
+    dof_1 = np.argmax(np.abs(U))
+    P = np.zeros((Nh, 1))
+    P[dof_1, 0] = 1.0
+    U = np.reshape(U, (Nh, 1))
+    interpolation_dofs = [dof_1]
+    Ns = Vf.shape[1]
+    for idx in range(1, Ns):
+        uj = np.reshape(Vf[:, idx], (Nh, 1))
+        matrix = np.matmul(P.T, U)
+        b = np.matmul(P.T, uj)
+        coeff = np.linalg.solve(matrix, b)
+        residual = uj - np.matmul(U, coeff)
+        dof_idx = np.argmax(np.abs(residual))
+        e_idx = np.zeros((Nh, 1))
+        e_idx[dof_idx, 0] = 1.0
+        P = np.hstack((P, e_idx))
+        U = np.hstack((U, uj))
+        interpolation_dofs.append(dof_idx)
+    return interpolation_dofs, P
+
+
+def deim_greedy(Vf):
+    """Gather form of deim.py:517-561 (P^T U == U[idx, :] exactly: products by 0/1).
+
+    Returns (dofs int64[m], PT_U float64[m, m], margin float64[m]) where
+    margin[k] = (top1 - top2) / top1 of |residual| at step k (0.0 = exact tie;
+    np.argmax then keeps the lowest index, deim.py:531,553).
+    """
+    Vf = np.asarray(Vf)
+    Nh, Ns = Vf.shape
+    dofs = np.empty(Ns, dtype=np.int64)
+    margin = np.empty(Ns)
+
+    def _pick(r):
+        a = np.abs(r)
+        i = int(np.argmax(a))
+        top = a[i]
+        a2 = a.copy()
+        a2[i] = -1.0
+        second = a2.max() if Nh > 1 else 0.0
+        return i, ((top - second) / top if top > 0 else 0.0)
+
+    dofs[0], margin[0] = _pick(Vf[:, 0])
+    for k in range(1, Ns):
+        idx = dofs[:k]
+        matrix = Vf[idx, :k]
+        b = Vf[idx, k]
+        coeff = np.linalg.solve(matrix, b)
+        residual = Vf[:, k] - np.matmul(Vf[:, :k], coeff)
+        dofs[k], margin[k] = _pick(residual)
+    PT_U = Vf[dofs, :]  # deim.py:159,212
+    return dofs, PT_U, margin
+
+
+# ---------------------------------------------------------------------------
+# a5  theta solve + interpolation -- deim.py:416-452,477-493 ; mdeim.py:230-261
+# ---------------------------------------------------------------------------
+def compute_thetas(PT_U, rhs):
+    return np.linalg.solve(PT_U, rhs)  # deim.py:491-492
+
+
+def interpolate(Vf, PT_U, fh_local, mdeim_fom_hack=False):
+    """deim.py:436-452: approx = sum_i theta_i Vf[:, i]; FOM-form MDEIM sets [0]=1."""
+    thetas = compute_thetas(PT_U, fh_local)
+    N = Vf.shape[1]
+    approximation = np.sum([thetas[i] * Vf[:, i] for i in range(N)], axis=0)
+    if mdeim_fom_hack:  # deim.py:449-450, nonlinear.py:280-281
+        approximation[0] = 1.0
+    return approximation
+
+
+# ---------------------------------------------------------------------------
+# a6/a7/a8  projections -- utils.py:96-113,136-149 ; deim.py:495-515 ; mdeim.py:153-192
+# ---------------------------------------------------------------------------
+def vector_to_csr(entries, rows, cols):
+    return csr_matrix((entries, (rows, cols)))  # utils.py:149
+
+
+def project_csr(Ah, V):
+    AhV = Ah.dot(V)  # utils.py:111
+    return np.matmul(V.T, AhV)  # utils.py:112
+
+
+def deim_project_basis(basis_fom, V):
+    return np.matmul(V.T, basis_fom)  # deim.py:509
+
+
+def mdeim_project_basis(basis_fom, rows, cols, V):
+    """mdeim.py:153-192: column i = flatten(V^T A_i V), A_i rebuilt from mode i."""
+    VfN = []
+    for i in range(basis_fom.shape[1]):
+        mat = vector_to_csr(basis_fom[:, i], rows, cols)
+        VfN.append(project_csr(mat, V).flatten())
+    return np.array(VfN).T
+
+
+def eliminate_zeros(Ah):
+    """utils.py:152-168 (mutates and returns Ah, like the reference)."""
+    mask = np.isclose(Ah.data, 0, rtol=ZERO_TOLERANCE, atol=ZERO_TOLERANCE)
+    Ah.data[mask] = 0
+    Ah.eliminate_zeros()
+    return Ah
+
+
+def get_matrix_topology(Ah):
+    """mdeim.py:126-151: scipy.sparse.find + stable sort by row."""
+    from scipy.sparse import find
+
+    Ah = eliminate_zeros(Ah.copy())
+    rows, cols, _ = find(Ah)
+    rows_cols = sorted(zip(rows, cols), key=lambda x: x[0])
+    return [x[0] for x in rows_cols], [x[1] for x in rows_cols]
+
+
+# ---------------------------------------------------------------------------
+# a13  error metrics -- rom/base.py:52-73 ; utils.py:173-212
+# ---------------------------------------------------------------------------
+def compute_error(u, ue):
+    e = u - ue
+    return np.linalg.norm(e, ord=2) / np.sqrt(len(u))
+
+
+def compute_rom_difference(uN, uN_srom, V_srom):
+    extra = len(uN_srom) - len(uN)
+    _uN = np.append(uN, extra * [0.0])
+    diff = uN_srom - _uN
+    lincomb = np.sum(diff * V_srom, axis=1)
+    return np.linalg.norm(lincomb, ord=2) / np.sqrt(len(lincomb))
+
+
+# ---------------------------------------------------------------------------
+# a9-a11  reduced assembly + solve + BDF loop -- rom/rom.py:430-555,877-929
+# ---------------------------------------------------------------------------
+def reduced_solve(KN, bN):
+    """rom.py:36,414-425,492: GMRES(20) on the dense system, info discarded."""
+    uN, _info = gmres(KN, bN, **GMRES_OPTIONS)
+    return uN
+
+
+def assemble_system(MN, AN, CN, NN, NhatN, bdf, dt):
+    """rom.py:905-907."""
+    return bdf * MN + dt * (AN + CN + NN + NhatN)
+
+
+def assemble_system_rhs(MN, fgN, uN_n, uN_n1, dt):
+    """rom.py:911-929."""
+    if uN_n1 is None:
+        bdf = MN.dot(uN_n)
+    else:
+        bdf = MN.dot(2.0 * uN_n - 0.5 * uN_n1)
+    return bdf + dt * fgN
+
+
+def rom_solve_nonlinear(fom, V, mu, solver=reduced_solve):
+    """The online loop of RomConstructorNonlinear, direct (non hyper-reduced) path.
+
+    Restates rom.py:430-555 with assemble_system/assemble_system_rhs of
+    rom.py:877-929 and to_rom of rom.py:135-158.  ``fom`` is duck-typed:
+    ``dt``, ``nt``, ``bdf2`` (bool), ``assemble_{mass,stiffness,convection,
+    nonlinear_lifting}(mu,t) -> csr``, ``assemble_trilinear(mu,t,u_n) -> csr``,
+    ``assemble_lifting(mu,t) -> ndarray``, ``lifting(mu,t) -> ndarray`` (g_h).
+    Returns (rom r x nt, fom N_h x nt).
+    """
+    r = V.shape[1]
+    dt = fom.dt
+    t = 0.0
+    uN_n = np.zeros(r)  # rom.py:451-453 (zero initial condition)
+    uh = V.dot(uN_n)
+    uh_n1 = None
+    uN_n1 = np.zeros_like(uN_n) if fom.bdf2 else None
+    rom_coeffs, fom_coeffs = [], []
+    for timestep in range(fom.nt):
+        t += dt
+        bdf = 1.5 if (fom.bdf2 and timestep > 0) else 1.0  # rom.py:481-483
+        MN = project_csr(fom.assemble_mass(mu, t), V)
+        AN = project_csr(fom.assemble_stiffness(mu, t), V)
+        CN = project_csr(fom.assemble_convection(mu, t), V)
+        u_star = uh if uh_n1 is None else 2.0 * uh - uh_n1  # rom.py:897-901
+        NN = project_csr(fom.assemble_trilinear(mu, t, u_star), V)
+        NhatN = project_csr(fom.assemble_nonlinear_lifting(mu, t), V)
+        KN = assemble_system(MN, AN, CN, NN, NhatN, bdf, dt)
+        fgN = V.T.dot(fom.assemble_lifting(mu, t))
+        bN = assemble_system_rhs(MN, fgN, uN_n, uN_n1, dt)
+        uN = solver(KN, bN)
+        rom_coeffs.append(uN)
+        uh = V.dot(uN)
+        if fom.bdf2:  # rom.py:499-502
+            uN_n1 = uN_n.copy()
+            uh_n1 = V.dot(uN_n1)
+        uN_n = uN.copy()
+        fom_coeffs.append(uh + fom.lifting(mu, t))
+    return np.vstack(rom_coeffs).T, np.vstack(fom_coeffs).T

@@ -1,0 +1,173 @@
+"""Closed-form 1-D P1 full-order models (NumPy/SciPy, no FEniCS).
+
+These stand where the reference's FEniCS solvers stand in its tests
+(``src/romtime/testing/mock.py:6-144`` for the linear operators,
+``src/romtime/fom/nonlinear.py:322-494`` for the Burgers/piston forms): they
+serve the ``assemble_*(mu, t[, entries][, u_n])`` callbacks the (M)DEIM and ROM
+classes call, returning ``scipy.sparse.csr_matrix`` / ``numpy.ndarray`` instead
+of dolfin objects.  Element matrices are the exact P1 integrals on a uniform
+interval mesh of ``nx`` cells scaled to ``[0, L(t)]``:
+
+    mass        h/6 [[2, 1], [1, 2]]
+    stiffness   alpha/h [[1, -1], [-1, 1]],   alpha = alpha_0 (1 + t^2)   (mock.py:30-48)
+    convection  -int u' v  = -1/2 [[-1, 1], [-1, 1]]                        (mock.py:69-85)
+    trilinear   int w u' v,  w = u_n linear on the cell                     (fom/nonlinear.py:398-418)
+
+Homogeneous Dirichlet rows (first and last dof) are replaced by identity rows,
+as ``DirichletBC.apply`` does (``fom/base.py:501-521``); local (entry-wise)
+assembly returns 1.0 / 0.0 on those (``fom/base.py:536-546``).
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.sparse import csr_matrix
+
+
+class MockSolver:
+    """Linear 1-D P1 operators on a (possibly moving) interval."""
+
+    DIRICHLET_ENTRY = 1.0  # fom/base.py:49
+    DIRICHLET_VALUE = 0.0  # fom/base.py:50
+    BDF_SCHEME = "2"
+    RUNTIME_PROCESS = False
+
+    def __init__(self, domain, forcing_term=None, Lt=None):
+        self.domain = dict(domain)
+        self.forcing_term = forcing_term  # callable f(x, t, **mu) or None
+        self.Lt = Lt  # callable L(t, **mu) -> scale factor, or None (fixed mesh)
+        self.is_setup = False
+        self.exact_solution = None
+        self.mu = None
+
+    # -- bookkeeping the ROM classes touch ---------------------------------
+    def setup(self):
+        self.nx = int(self.domain["nx"])
+        self.Nh = self.nx + 1
+        self.is_setup = True
+
+    def update_parametrization(self, new):
+        self.mu = dict(new)
+
+    @property
+    def dt(self):
+        return self.domain["T"] / self.domain["nt"]
+
+    def _L(self, mu, t):
+        L0 = self.domain["L0"]
+        return L0 * (self.Lt(t=t, **mu) if self.Lt is not None else 1.0)
+
+    def x_at(self, mu, t):
+        return np.linspace(0.0, self._L(mu, t), self.Nh)
+
+    # -- element-level assembly ---------------------------------------------
+    def _assemble_matrix(self, elem, entries):
+        """elem: (nx, 2, 2) element matrices.  Global CSR or values at entries."""
+        nx, Nh = self.nx, self.Nh
+        if entries is not None:
+            out = np.empty(len(entries))
+            for k, (i, j) in enumerate(entries):
+                if i in (0, Nh - 1):
+                    out[k] = self.DIRICHLET_ENTRY if i == j else 0.0
+                    continue
+                v = 0.0
+                for e in (i - 1, i):  # cells touching dof i
+                    if 0 <= e < nx and e <= j <= e + 1:
+                        v += elem[e, i - e, j - e]
+                out[k] = v
+            return out
+        e = np.arange(nx)
+        rows = np.concatenate([e, e, e + 1, e + 1])
+        cols = np.concatenate([e, e + 1, e, e + 1])
+        vals = np.concatenate([elem[:, 0, 0], elem[:, 0, 1], elem[:, 1, 0], elem[:, 1, 1]])
+        keep = (rows != 0) & (rows != Nh - 1)
+        rows = np.concatenate([rows[keep], [0, Nh - 1]])
+        cols = np.concatenate([cols[keep], [0, Nh - 1]])
+        vals = np.concatenate([vals[keep], [1.0, 1.0]])
+        A = csr_matrix((vals, (rows, cols)), shape=(Nh, Nh))
+        A.sum_duplicates()
+        A.sort_indices()
+        return A
+
+    def _assemble_vector(self, elem, entries):
+        """elem: (nx, 2) element vectors."""
+        nx, Nh = self.nx, self.Nh
+        f = np.zeros(Nh)
+        np.add.at(f, np.arange(nx), elem[:, 0])
+        np.add.at(f, np.arange(nx) + 1, elem[:, 1])
+        f[0] = f[-1] = self.DIRICHLET_VALUE
+        if entries is not None:
+            return np.array([f[i] for (i,) in entries])
+        return f
+
+    def _h(self, mu, t):
+        return self._L(mu, t) / self.nx
+
+    def assemble_mass(self, mu=None, t=None, entries=None):
+        h = self._h(mu, t)
+        elem = np.tile(h / 6.0 * np.array([[2.0, 1.0], [1.0, 2.0]]), (self.nx, 1, 1))
+        return self._assemble_matrix(elem, entries)
+
+    def assemble_stiffness(self, mu=None, t=None, entries=None):
+        h = self._h(mu, t)
+        alpha = mu["alpha_0"] * (1.0 + t * t)
+        elem = np.tile(alpha / h * np.array([[1.0, -1.0], [-1.0, 1.0]]), (self.nx, 1, 1))
+        return self._assemble_matrix(elem, entries)
+
+    def assemble_convection(self, mu=None, t=None, entries=None):
+        elem = np.tile(-0.5 * np.array([[-1.0, 1.0], [-1.0, 1.0]]), (self.nx, 1, 1))
+        return self._assemble_matrix(elem, entries)
+
+    def assemble_forcing(self, mu, t, entries=None):
+        x = self.x_at(mu, t)
+        h = self._h(mu, t)
+        fx = self.forcing_term(x, t, **mu)
+        fa, fb = fx[:-1], fx[1:]
+        elem = np.stack([h / 6.0 * (2.0 * fa + fb), h / 6.0 * (fa + 2.0 * fb)], axis=1)
+        return self._assemble_vector(elem, entries)
+
+    def assemble_lifting(self, mu, t, entries=None):
+        return np.zeros(self.Nh) if entries is None else np.zeros(len(entries))
+
+
+class MockBurgers(MockSolver):
+    """Burgers/piston-type operators for the online loop (rom/rom.py:877-929).
+
+    ``mu`` keys: ``alpha_0`` (viscosity), ``delta``, ``omega`` (lifting motion).
+    """
+
+    def __init__(self, domain, Lt=None, bdf2=True):
+        super().__init__(domain=domain, forcing_term=None, Lt=Lt)
+        self.bdf2 = bdf2
+        self.BDF_SCHEME = "2" if bdf2 else "1"
+
+    @property
+    def nt(self):
+        return int(self.domain["nt"])
+
+    def _trilinear_elem(self, w):
+        wa, wb = w[:-1], w[1:]
+        a = (2.0 * wa + wb) / 6.0
+        b = (wa + 2.0 * wb) / 6.0
+        return np.stack([np.stack([-a, a], axis=1), np.stack([-b, b], axis=1)], axis=1)
+
+    def assemble_trilinear(self, mu, t, u_n, entries=None):
+        return self._assemble_matrix(self._trilinear_elem(np.asarray(u_n)), entries)
+
+    def lifting(self, mu, t):
+        """Nodal values g_h of the lifting function on the moved mesh."""
+        x = self.x_at(mu, t)
+        L = self._L(mu, t)
+        amp = mu["delta"] * np.sin(mu["omega"] * t)
+        return amp * x / L
+
+    def assemble_nonlinear_lifting(self, mu, t, entries=None):
+        return self._assemble_matrix(self._trilinear_elem(self.lifting(mu, t)), entries)
+
+    def assemble_lifting(self, mu, t, entries=None):
+        x = self.x_at(mu, t)
+        h = self._h(mu, t)
+        L = self._L(mu, t)
+        gdot = -mu["delta"] * mu["omega"] * np.cos(mu["omega"] * t) * x / L
+        fa, fb = gdot[:-1], gdot[1:]
+        elem = np.stack([h / 6.0 * (2.0 * fa + fb), h / 6.0 * (fa + 2.0 * fb)], axis=1)
+        return self._assemble_vector(elem, entries)

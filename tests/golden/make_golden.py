@@ -1,0 +1,430 @@
+#!/usr/bin/env python3
+"""Generate ``tests/golden/*.npz`` by RUNNING THE REFERENCE'S OWN SOURCE.
+
+Run in the build container only (``python tests/golden/make_golden.py``); it
+reads ``/root/reference/src`` by path and is a no-op where that does not exist.
+Nothing of the reference is copied: the fixtures hold seeded inputs, the
+reference's outputs on them, and the library versions that produced them.
+
+How the reference is loaded:
+  * ``rom/pod.py`` needs only numpy+scipy and is loaded by file path;
+  * the other modules import FEniCS at module scope, which is not installed, so
+    inert placeholder modules named ``fenics``, ``dolfin.cpp.la`` (with empty
+    ``Matrix``/``Vector`` classes), ``ujson``, ``seaborn``, ``adjustText`` are
+    registered first -- no FEniCS function is ever called by the hot path;
+  * two NumPy/SciPy API drifts are bridged here and only here:
+    ``np.reshape(a=, newshape=)`` (deim.py:535) and ``gmres(tol=, maxiter=1e6)``
+    (rom.py:36).
+"""
+import os
+import sys
+import types
+import importlib.util
+
+import numpy as np
+import scipy
+import scipy.sparse.linalg
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference/src"
+sys.path.insert(0, REPO)
+
+
+def _versions():
+    return dict(numpy=np.__version__, scipy=scipy.__version__)
+
+
+def load_reference():
+    # --- placeholders for absent third-party modules -----------------------
+    class Matrix:  # dolfin.cpp.la.Matrix stand-in: wraps a scipy CSR
+        def __init__(self, csr):
+            self._csr = csr.tocsr()
+
+        # what bilinear_to_csr touches (utils.py:90-91)
+        def mat(self):
+            return self
+
+        def getValuesCSR(self):
+            c = self._csr
+            return c.indptr, c.indices, c.data
+
+        @property
+        def size(self):
+            return self._csr.shape
+
+    class Vector:  # dolfin.cpp.la.Vector stand-in: wraps an ndarray
+        def __init__(self, arr):
+            self._arr = np.asarray(arr, dtype=float)
+
+        def __array__(self, dtype=None, copy=None):
+            return self._arr
+
+        def __len__(self):
+            return len(self._arr)
+
+    fenics = types.ModuleType("fenics")
+    fenics.as_backend_type = lambda m: m
+    fenics.DOLFIN_EPS = 3e-16
+    dolfin = types.ModuleType("dolfin")
+    dolfin_cpp = types.ModuleType("dolfin.cpp")
+    dolfin_la = types.ModuleType("dolfin.cpp.la")
+    dolfin_la.Matrix = Matrix
+    dolfin_la.Vector = Vector
+    dolfin.cpp = dolfin_cpp
+    dolfin_cpp.la = dolfin_la
+    for name, mod in [("fenics", fenics), ("dolfin", dolfin), ("dolfin.cpp", dolfin_cpp),
+                      ("dolfin.cpp.la", dolfin_la), ("ujson", types.ModuleType("ujson")),
+                      ("seaborn", types.ModuleType("seaborn"))]:
+        sys.modules[name] = mod
+    adj = types.ModuleType("adjustText")
+    adj.adjust_text = lambda *a, **k: None
+    sys.modules["adjustText"] = adj
+
+    # --- API drift shims (generator only) ----------------------------------
+    _reshape = np.reshape
+
+    def reshape(*args, **kwargs):
+        if "a" in kwargs:
+            args = (kwargs.pop("a"),) + args
+        if "newshape" in kwargs:
+            kwargs["shape"] = kwargs.pop("newshape")
+        return _reshape(*args, **kwargs)
+
+    np.reshape = reshape
+    _gmres = scipy.sparse.linalg.gmres
+
+    def gmres(A, b, tol=None, maxiter=None, **kw):
+        if tol is not None:
+            kw["rtol"] = tol
+        if maxiter is not None:
+            maxiter = int(maxiter)
+        return _gmres(A, b, maxiter=maxiter, **kw)
+
+    scipy.sparse.linalg.gmres = gmres
+
+    sys.path.insert(0, REF)
+    import matplotlib
+
+    matplotlib.use("Agg")
+    spec = importlib.util.spec_from_file_location("ref_pod", os.path.join(REF, "romtime/rom/pod.py"))
+    ref_pod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref_pod)
+    import romtime.deim as ref_deim
+    import romtime.rom.rom as ref_rom
+    import romtime.rom.base as ref_base
+    import romtime.utils as ref_utils
+
+    return types.SimpleNamespace(pod=ref_pod, deim=ref_deim, rom=ref_rom, base=ref_base,
+                                 utils=ref_utils, Matrix=Matrix, Vector=Vector)
+
+
+# ---------------------------------------------------------------------------
+# seeded inputs (shared with the tests through the .npz files themselves)
+# ---------------------------------------------------------------------------
+def spectrum_matrix(rng, N, n, sigmas):
+    U0, _ = np.linalg.qr(rng.standard_normal((N, n)))
+    V0, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    return (U0 * sigmas) @ V0.T
+
+
+def smooth_snapshots(N, n):
+    """Config-1-like smooth parametrised snapshots (fast singular value decay)."""
+    x = np.linspace(0.0, 1.0, N)
+    ts = np.linspace(0.05, 5.0, n)
+    cols = [(1.0 - np.exp(-0.7 * t)) * (1.0 + (0.3 + 0.1 * t) * x * x) * np.sin(np.pi * x * (1 + 0.05 * t))
+            for t in ts]
+    return np.array(cols).T
+
+
+def gen_orth(ref, out):
+    rng = np.random.RandomState(20260104)
+    mats = {}
+    mats["random_120x10"] = rng.standard_normal((120, 10))
+    mats["decay_200x16"] = spectrum_matrix(rng, 200, 16, 10.0 ** (-np.arange(16) * 0.5))
+    m = spectrum_matrix(rng, 160, 14, np.r_[10.0 ** (-np.arange(7) * 0.5), 10.0 ** (-9.0 - np.arange(7) * 0.5)])
+    mats["gap_1e-7_160x14"] = m  # singular values straddle DROP_TOLERANCE with a clear gap
+    z = spectrum_matrix(rng, 129, 12, 10.0 ** (-np.arange(12) * 0.4))
+    z[0, :] = 0.0  # MDEIM convention: row 0 zeroed (deim.py:388-389)
+    mats["zero_row_129x12"] = z
+    mats["smooth_401x40"] = smooth_snapshots(401, 40)
+    # an F-ordered view, as np.array(list_of_vectors).T produces (deim.py:384)
+    mats["fview_90x8"] = np.array([rng.standard_normal(90) for _ in range(8)]).T
+    branches = {
+        "drop": dict(),
+        "num": dict(num=5),
+        "tol": dict(tol=1.0 - 1e-6),
+        "tol_num": dict(tol=0.999, num=3),  # tol has precedence (pod.py:46-53)
+    }
+    data = {}
+    cases = []
+    for mname, X in mats.items():
+        data[f"X__{mname}"] = X
+        for bname, kw in branches.items():
+            for normalize in (True, False):
+                Q, s, energy, VT = ref.pod.orth(X.copy(), normalize=normalize, return_VT=True, **kw)
+                key = f"{mname}__{bname}__{'norm' if normalize else 'raw'}"
+                cases.append(key)
+                data[f"Q__{key}"] = Q
+                data[f"s__{key}"] = s
+                data[f"energy__{key}"] = energy
+                data[f"VT__{key}"] = VT
+    data["cases"] = np.array(cases)
+    data["versions"] = np.array(repr(_versions()))
+    np.savez_compressed(os.path.join(out, "orth.npz"), **data)
+    print("orth.npz:", len(cases), "cases")
+
+
+def mdeim_p1_basis(ref):
+    """Collateral basis of P1 stiffness+mass value-vectors on a tridiagonal pattern."""
+    from romtime_amd.testing.mock import MockBurgers
+
+    fom = MockBurgers(domain=dict(L0=1.0, nx=60, T=5.0, nt=20), Lt=lambda t, **mu: 1.0 + 0.2 * t * mu["delta"])
+    fom.setup()
+    rng = np.random.RandomState(3)
+    snaps = []
+    for _ in range(12):
+        mu = dict(alpha_0=rng.uniform(0.01, 2.0), delta=rng.uniform(0.01, 2.0))
+        for t in np.linspace(0.1, 5.0, 6):
+            w = np.sin((1.0 + mu["delta"]) * np.pi * fom.x_at(mu, t) * (1.0 + 0.3 * t)) * mu["alpha_0"]
+            A = (fom.assemble_stiffness(mu, t) + fom.assemble_mass(mu, t) * (1 + t)
+                 + mu["delta"] * fom.assemble_convection(mu, t) + fom.assemble_trilinear(mu, t, w))
+            snaps.append(A.data.copy())
+    S = np.array(snaps).T
+    S[0, :] = 0.0
+    basis, _, _ = ref.pod.orth(S, normalize=False)
+    A = fom.assemble_stiffness(dict(alpha_0=1.0, delta=1.0), 1.0)
+    rows, cols = A.nonzero()
+    order = np.argsort(rows, kind="stable")
+    return basis, rows[order], cols[order], fom
+
+
+def gen_deim(ref, out):
+    rng = np.random.RandomState(20260105)
+    DEIM = ref.deim.DiscreteEmpiricalInterpolation
+    MDEIM = ref.deim.MatrixDiscreteEmpiricalInterpolation
+    data = {}
+
+    def greedy(basis):
+        d = DEIM(assemble=None, name="golden")
+        d.basis_fom = basis
+        dofs, P = d.build_interpolation_mesh()
+        return np.array(dofs, dtype=np.int64), np.matmul(P.T, basis)
+
+    def margins(basis, dofs):
+        m = np.empty(len(dofs))
+        for k in range(len(dofs)):
+            if k == 0:
+                r = basis[:, 0]
+            else:
+                c = np.linalg.solve(basis[dofs[:k], :k], basis[dofs[:k], k])
+                r = basis[:, k] - basis[:, :k] @ c
+            a = np.sort(np.abs(r))[::-1]
+            m[k] = (a[0] - a[1]) / a[0]
+        return m
+
+    bases = {}
+    bases["random_orth_300x16"], _ = np.linalg.qr(rng.standard_normal((300, 16)))
+    # mirror-symmetric FE-like data: exact ties between i and N-1-i (SURVEY hard part C)
+    x = np.linspace(0.0, 1.0, 201)
+    sym = np.array([np.cos(2 * np.pi * k * (x - 0.5)) * np.exp(-k * 0.1) for k in range(1, 9)]).T
+    bases["mirror_201x8"], _, _ = ref.pod.orth(sym, normalize=False)
+    p1, rows, cols, fom = mdeim_p1_basis(ref)
+    bases["mdeim_p1"] = p1
+    bases["smooth_pod_401"] = ref.pod.orth(smooth_snapshots(401, 40), num=10)[0]
+    for name, B in bases.items():
+        B = np.ascontiguousarray(B)
+        dofs, PT_U = greedy(B)
+        data[f"basis__{name}"] = B
+        data[f"dofs__{name}"] = dofs
+        data[f"PT_U__{name}"] = PT_U
+        data[f"margin__{name}"] = margins(B, dofs)
+    data["names"] = np.array(list(bases))
+
+    # --- project_basis (DEIM: deim.py:495-515; MDEIM: mdeim.py:153-192) --------
+    V, _ = np.linalg.qr(rng.standard_normal((p1.shape[0] * 0 + fom.Nh, 8)))
+    md = MDEIM(assemble=None, name="golden")
+    md.basis_fom = p1[:, :5].copy()
+    md.rows, md.cols = list(rows), list(cols)
+    md.project_basis(V)
+    data["mdeim_V"] = V
+    data["mdeim_rows"] = rows.astype(np.int64)
+    data["mdeim_cols"] = cols.astype(np.int64)
+    data["mdeim_basis_fom"] = md.basis_fom
+    data["mdeim_basis_rom"] = md.basis_rom
+    data["mdeim_N_V"] = np.array(md.N_V)
+
+    dd = DEIM(assemble=None, name="golden")
+    dd.basis_fom = bases["random_orth_300x16"]
+    V2, _ = np.linalg.qr(rng.standard_normal((300, 7)))
+    dd.project_basis(V2)
+    data["deim_V"] = V2
+    data["deim_basis_rom"] = dd.basis_rom
+
+    # --- _interpolate FOM / ROM form (deim.py:416-452, mdeim.py:230-261) -------
+    md.load_fom_basis(basis=p1[:, :5].copy())  # re-runs greedy, stores dofs/PT_U
+    md.project_basis(V)
+    truth = p1[:, :5] @ rng.standard_normal(5)
+    md.assemble = lambda mu, t, entries=None: np.array([truth[list(zip(rows, cols)).index(e)] for e in entries])
+    data["interp_truth"] = truth
+    data["interp_dofs_rc"] = np.array(md.dofs, dtype=np.int64)
+    data["interp_PT_U"] = md.PT_U
+    data["interp_fom"] = md._interpolate(mu={}, t=0.0, which=md.FOM)
+    data["interp_rom"] = md.interpolate(mu={}, t=0.0, which=md.ROM)
+    data["interp_thetas"] = md.compute_thetas(np.array([truth[list(zip(rows, cols)).index(e)] for e in md.dofs]))
+    dd.load_fom_basis(basis=bases["random_orth_300x16"].copy())
+    dd.project_basis(V2)
+    tv = bases["random_orth_300x16"] @ rng.standard_normal(16)
+    dd.assemble = lambda mu, t, entries=None: np.array([tv[i] for (i,) in entries])
+    data["interp_vec_truth"] = tv
+    data["interp_vec_fom"] = dd._interpolate(mu={}, t=0.0, which=dd.FOM)
+    data["interp_vec_rom"] = dd._interpolate(mu={}, t=0.0, which=dd.ROM)
+
+    # --- project_csr / eliminate_zeros (utils.py:96-113,152-168) ----------------
+    A = fom.assemble_stiffness(dict(alpha_0=0.7, delta=0.3), 2.0)
+    data["csr_indptr"] = A.indptr.astype(np.int64)
+    data["csr_indices"] = A.indices.astype(np.int64)
+    data["csr_data"] = A.data
+    data["project_csr"] = ref.utils.project_csr(A, V)
+    B = A.copy()
+    B.data[::7] = 5e-16
+    B.data[3::11] = -1e-15
+    data["ez_data_in"] = B.data.copy()
+    B2 = ref.utils.eliminate_zeros(B.copy())
+    data["ez_indptr"] = B2.indptr.astype(np.int64)
+    data["ez_indices"] = B2.indices.astype(np.int64)
+    data["ez_data"] = B2.data
+
+    # --- error metrics (rom/base.py:52-73, utils.py:173-212) -------------------
+    u, ue = rng.standard_normal(37), rng.standard_normal(37)
+    data["err_u"], data["err_ue"] = u, ue
+    data["err"] = np.array(ref.base.Reductor._compute_error(u, ue))
+    uN, uNs, Vs = rng.standard_normal(4), rng.standard_normal(7), rng.standard_normal((10, 7))
+    data["diff_uN"], data["diff_uNs"], data["diff_Vs"] = uN, uNs, Vs
+    data["diff"] = np.array(ref.utils.compute_rom_difference(uN, uNs, Vs))
+    data["versions"] = np.array(repr(_versions()))
+    np.savez_compressed(os.path.join(out, "deim.npz"), **data)
+    print("deim.npz:", list(bases))
+
+
+class RefFomAdapter:
+    """Presents a MockBurgers to the reference's RomConstructorNonlinear.solve."""
+
+    probe_location = []
+    RUNTIME_PROCESS = False
+    exact_solution = None
+
+    def __init__(self, ref, fom):
+        self._ref, self._fom = ref, fom
+        self.BDF_SCHEME = fom.BDF_SCHEME
+        self.domain = fom.domain
+        self.dt = fom.dt
+        self.V = None
+        self.L = None
+        self.is_setup = True
+        self._cur = None
+
+    def move_mesh(self, mu=None, t=None, back=False):
+        self._cur = None if back else (mu, t)
+
+    @property
+    def x(self):
+        mu, t = self._cur
+        return self._fom.x_at(mu, t).reshape(-1, 1)
+
+    def create_lifting_operator(self, mu, t, L):
+        return (mu, t), None, None
+
+    def interpolate_func(self, g, V, mu, t):
+        arr = self._fom.lifting(mu, t)
+        vec = types.SimpleNamespace(array=arr)
+        return types.SimpleNamespace(vector=lambda: types.SimpleNamespace(vec=lambda: vec))
+
+    def _mat(self, A):
+        return self._ref.Matrix(A)
+
+    def assemble_mass(self, mu, t):
+        return self._mat(self._fom.assemble_mass(mu, t))
+
+    def assemble_stiffness(self, mu, t):
+        return self._mat(self._fom.assemble_stiffness(mu, t))
+
+    def assemble_convection(self, mu, t):
+        return self._mat(self._fom.assemble_convection(mu, t))
+
+    def assemble_trilinear(self, mu, t, u_n):
+        return self._mat(self._fom.assemble_trilinear(mu, t, u_n))
+
+    def assemble_nonlinear_lifting(self, mu, t):
+        return self._mat(self._fom.assemble_nonlinear_lifting(mu, t))
+
+    def assemble_lifting(self, mu, t):
+        return self._ref.Vector(self._fom.assemble_lifting(mu, t))
+
+
+def gen_rom(ref, out):
+    from romtime_amd.testing.mock import MockBurgers
+
+    rng = np.random.RandomState(20260106)
+    data = {}
+    cases = []
+    for r in (10, 24):
+        for bdf2 in (False, True):
+            fom = MockBurgers(domain=dict(L0=1.0, nx=120, T=0.5, nt=50),
+                              Lt=lambda t, **mu: 1.0 - 0.1 * np.sin(mu["omega"] * t), bdf2=bdf2)
+            fom.setup()
+            x = np.linspace(0, 1, fom.Nh)
+            modes = np.array([np.sin((k + 1) * np.pi * x) for k in range(r)]).T
+            modes += 1e-3 * rng.standard_normal(modes.shape)
+            modes[0, :] = modes[-1, :] = 0.0
+            V, _ = np.linalg.qr(modes)
+            mu = dict(alpha_0=0.05, delta=0.3, omega=9.0)
+            rom = ref.rom.RomConstructorNonlinear(fom=RefFomAdapter(ref, fom), grid=None, name="golden")
+            rom.setup(rnd=0)
+            rom.basis = V
+            rom.solve(mu=mu, step="online")
+            key = f"r{r}_bdf{2 if bdf2 else 1}"
+            cases.append(key)
+            data[f"V__{key}"] = V
+            data[f"rom__{key}"] = rom.solutions.rom
+            data[f"fom__{key}"] = rom.solutions.fom
+            data[f"ts__{key}"] = np.array(rom.solutions.ts)
+    data["cases"] = np.array(cases)
+    data["mu"] = np.array([0.05, 0.3, 9.0])  # alpha_0, delta, omega
+    data["versions"] = np.array(repr(_versions()))
+    np.savez_compressed(os.path.join(out, "rom.npz"), **data)
+    print("rom.npz:", cases)
+
+
+def gen_sampler(ref, out):
+    from sklearn.model_selection import ParameterSampler
+    import sklearn
+
+    sys.path.insert(0, REF)
+    from romtime.parameters import get_uniform_dist
+
+    grid = {"delta": get_uniform_dist(min=0.01, max=2.0), "beta": get_uniform_dist(min=1.0, max=10.0),
+            "alpha_0": get_uniform_dist(min=0.01, max=2.0)}  # tests/test_mdeim.py:43-47
+    red = ref.base.Reductor(grid=grid)
+    red.setup(rnd=np.random.RandomState(0))
+    draws = list(red.build_sampling_space(num=8, rnd=np.random.RandomState(0)))
+    keys = sorted(draws[0])
+    arr = np.array([[d[k] for k in keys] for d in draws])
+    np.savez_compressed(os.path.join(out, "sampler.npz"), keys=np.array(keys), draws=arr,
+                        versions=np.array(repr(dict(sklearn=sklearn.__version__, **_versions()))))
+    print("sampler.npz:", arr.shape)
+
+
+def main():
+    if not os.path.isdir(REF):
+        print("reference not present; nothing to do")
+        return
+    ref = load_reference()
+    gen_orth(ref, HERE)
+    gen_deim(ref, HERE)
+    gen_rom(ref, HERE)
+    gen_sampler(ref, HERE)
+
+
+if __name__ == "__main__":
+    main()
