@@ -1,0 +1,128 @@
+/*
+ * romtime_hip.h -- C ABI of libromtime_hip.so (MI355X / gfx950).
+ *
+ * The reference (KikeM/romtime @ v0) has no FFI layer: its "operator API" is a
+ * Python class surface over NumPy/SciPy calls.  Each entry point
+ * below replaces one of those library call sites; the citation is the
+ * reference file:line (relative to /root/reference) it stands in for.
+ *
+ * Conventions
+ *   - every data pointer is a DEVICE pointer (hipMalloc'ed or a torch CUDA
+ *     tensor's data_ptr()); f64 = double, indices = int64_t;
+ *   - work is enqueued on the ctx's stream (rt_ctx_set_stream) and the call
+ *     returns without synchronising unless stated;
+ *   - return value: 0 ok, <0 argument / runtime error (rt_last_error has the
+ *     text), >0 numerical warning (RT_WARN_*); nothing throws;
+ *   - the caller owns all buffers; a ctx owns a scratch arena that grows on
+ *     demand (hipMalloc: not capturable on first use);
+ *   - one ctx per host thread; calls on one ctx are serialised by its stream.
+ */
+#ifndef ROMTIME_HIP_H
+#define ROMTIME_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_ctx rt_ctx;
+
+#define RT_OK 0
+#define RT_ERR_ARG (-1)
+#define RT_ERR_HIP (-2)
+#define RT_ERR_UNSUPPORTED (-3)
+#define RT_WARN_ZERO_NORM 1   /* zero-norm column in orth(normalize=True), pod.py:32-33 yields NaN */
+#define RT_WARN_SINGULAR 2    /* zero pivot in a dense solve */
+
+#define RT_ROW_MAJOR 0        /* element (i,j) at p[i*ld + j]  (NumPy C order)  */
+#define RT_COL_MAJOR 1        /* element (i,j) at p[j*ld + i]  (NumPy F order; np.array(list_of_vectors).T, deim.py:384) */
+
+int rt_version(void);
+int rt_ctx_create(rt_ctx** out, int device);
+void rt_ctx_destroy(rt_ctx* ctx);
+int rt_ctx_set_stream(rt_ctx* ctx, void* hip_stream);
+int rt_ctx_synchronize(rt_ctx* ctx);
+const char* rt_last_error(rt_ctx* ctx);
+/* dispatch statistics of the most recent GEMM-class launch: [0]=grid, [1]=splits, [2]=tile */
+int rt_last_launch_info(rt_ctx* ctx, int64_t* info3);
+
+/* ---- POD (src/romtime/rom/pod.py:7-62) ------------------------------------------------ */
+
+/* G = X^T X (n_cols x n_cols, row-major, full symmetric).  X is n_rows x n_cols with
+ * leading dimension ld in the given layout.  This is the local part of the snapshot
+ * Gram matrix: with row-sharded X the caller all-reduces G (RCCL) before rt_gram_scale.
+ * Replaces the O(N n^2) part of scipy.linalg.svd(..., lapack_driver="gesvd") (pod.py:38). */
+int rt_gram(rt_ctx* ctx, const double* X, int64_t n_rows, int64_t n_cols, int64_t ld, int layout,
+            double* G);
+
+/* colnorm[j] = sqrt(G[j][j]) (== np.linalg.norm(X, axis=0), pod.py:32); if normalize != 0,
+ * G <- D^-1 G D^-1 (the Gram matrix of np.divide(X, l2_norms), pod.py:33).  A zero norm
+ * propagates NaN exactly as the reference does and *status_flag (device int, may be NULL)
+ * is set to RT_WARN_ZERO_NORM. */
+int rt_gram_scale(rt_ctx* ctx, double* G, int64_t n, double* colnorm, int normalize, int* status_flag);
+
+/* C (m x n, row-major, ldc) = A^T B with A: N x m, B: N x n (each with ld + layout).
+ * np.matmul(V.T, AhV) (utils.py:112), np.matmul(V.T, Vfh) (deim.py:509), V.T.dot(f)
+ * (rom.py:133,156).  A == B with m == n computes only the upper triangle and mirrors it. */
+int rt_gemm_tn(rt_ctx* ctx, const double* A, int64_t lda, int a_layout, const double* B, int64_t ldb,
+               int b_layout, int64_t N, int64_t m, int64_t n, double* C, int64_t ldc);
+
+/* Y (N x k, ldy, y_layout) = X (N x n, ldx, x_layout) * T (n x k, row-major, ldt).
+ * The POD back-projection U_r = X (D^-1 W_r S_r^-1) and V.dot(uN) (rom.py:111-112). */
+int rt_gemm_nn(rt_ctx* ctx, const double* X, int64_t ldx, int x_layout, const double* T, int64_t ldt,
+               int64_t N, int64_t n, int64_t k, double* Y, int64_t ldy, int y_layout);
+
+/* Out-of-place transpose: dst (cols x rows, row-major, ld_dst) = src (rows x cols, row-major, ld_src)^T. */
+int rt_transpose(rt_ctx* ctx, const double* src, int64_t rows, int64_t cols, int64_t ld_src, double* dst,
+                 int64_t ld_dst);
+
+/* ---- DEIM (src/romtime/deim/deim.py:517-561, :159, :212) -------------------------------- */
+
+/* Greedy interpolation-index selection on the collateral basis Phi (N x m).
+ * idx[k] = argmax_i |phi_k - Phi[:, :k] c|, c = solve(Phi[idx[:k], :k], phi_k[idx[:k]]),
+ * first maximum on ties (np.argmax, deim.py:531,553).  PT_U (m x m row-major) = Phi[idx, :]
+ * (np.matmul(P.T, basis), deim.py:159,212).  margin (m, may be NULL) = (top1-top2)/top1 of
+ * |residual| per step.  Synchronises the stream before returning. */
+int rt_deim_greedy(rt_ctx* ctx, const double* Phi, int64_t N, int64_t m, int64_t ld, int layout,
+                   int64_t* idx, double* PT_U, double* margin);
+
+/* ---- projections (src/romtime/utils.py:96-113,136-149; deim/mdeim.py:153-192) ----------- */
+
+/* Y (N x r row-major, ldy) = A V, A in CSR (N rows), V (n_colsA x r row-major, ldv).
+ * scipy.sparse.csr_matrix.dot(dense) (utils.py:111). */
+int rt_csr_spmm(rt_ctx* ctx, const int64_t* indptr, const int64_t* indices, const double* data, int64_t N,
+                const double* V, int64_t ldv, int64_t r, double* Y, int64_t ldy);
+
+/* AN (r x r row-major) = V^T (A V)   (project_csr, utils.py:96-113). */
+int rt_project_csr(rt_ctx* ctx, const int64_t* indptr, const int64_t* indices, const double* data, int64_t N,
+                   const double* V, int64_t ldv, int64_t r, double* AN);
+
+/* Batched over B value-vectors on one fixed CSR pattern: data_batch holds B value vectors,
+ * vector b at data_batch + b*ld_data (stride 1) when data_layout == RT_COL_MAJOR, or element
+ * e of vector b at data_batch[e*ld_data + b] when RT_ROW_MAJOR (the (nnz x m) basis_fom array
+ * in C order).  AN_batch is B x r x r.  MDEIM.project_basis (mdeim.py:153-192) with
+ * vector_to_csr folded away (the pattern is already CSR-ordered, mdeim.py:145-149), and the
+ * online multi-parameter sweep. */
+int rt_project_csr_batched(rt_ctx* ctx, const int64_t* indptr, const int64_t* indices,
+                           const double* data_batch, int64_t ld_data, int data_layout, int64_t B, int64_t N,
+                           const double* V, int64_t ldv, int64_t r, double* AN_batch);
+
+/* ---- reduced solve (np.linalg.solve: deim.py:491-492; gmres on a dense r x r: rom.py:492) --- */
+
+/* Solve K_b x_b = rhs_b for b < B by LU with partial pivoting, one workgroup per system.
+ * K (B x r x r row-major) is overwritten with its factors, rhs (B x r) with x.
+ * info (B device ints, may be NULL): 0, or RT_WARN_SINGULAR. r <= 128. */
+int rt_dense_solve_batched(rt_ctx* ctx, double* K, double* rhs, int64_t r, int64_t B, int* info);
+
+/* ---- measurement helpers (not part of the reference surface) ------------------------------ */
+/* Runs `iters` back-to-back v_mfma_f64_16x16x4_f64 per wave on a full-chip grid and returns
+ * the achieved TFLOP/s in *tflops (synchronises). */
+int rt_bench_mfma_f64(rt_ctx* ctx, int iters, double* tflops);
+/* Device-to-device streaming copy of `bytes` bytes; returns GB/s (read+write) (synchronises). */
+int rt_bench_copy(rt_ctx* ctx, void* dst, const void* src, int64_t bytes, int reps, double* gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROMTIME_HIP_H */

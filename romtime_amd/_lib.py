@@ -1,0 +1,124 @@
+"""ctypes binding of libromtime_hip.so (declared in include/romtime_hip.h).
+
+There is no CPU fallback: if the library is missing or no MI355X is visible the hot-path
+entry points raise.  The only thing that works without a GPU is loading the library and
+inspecting its symbols (used by the CPU-side tests).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libromtime_hip.so")
+
+ROW_MAJOR, COL_MAJOR = 0, 1
+RT_OK = 0
+WARN_ZERO_NORM, WARN_SINGULAR = 1, 2
+
+_p = C.c_void_p
+_i64 = C.c_int64
+_int = C.c_int
+
+# name -> (restype, argtypes); mirrors include/romtime_hip.h one to one
+SIGNATURES = {
+    "rt_version": (_int, []),
+    "rt_ctx_create": (_int, [C.POINTER(_p), _int]),
+    "rt_ctx_destroy": (None, [_p]),
+    "rt_ctx_set_stream": (_int, [_p, _p]),
+    "rt_ctx_synchronize": (_int, [_p]),
+    "rt_last_error": (C.c_char_p, [_p]),
+    "rt_last_launch_info": (_int, [_p, C.POINTER(_i64)]),
+    "rt_gram": (_int, [_p, _p, _i64, _i64, _i64, _int, _p]),
+    "rt_gram_scale": (_int, [_p, _p, _i64, _p, _int, _p]),
+    "rt_gemm_tn": (_int, [_p, _p, _i64, _int, _p, _i64, _int, _i64, _i64, _i64, _p, _i64]),
+    "rt_gemm_nn": (_int, [_p, _p, _i64, _int, _p, _i64, _i64, _i64, _i64, _p, _i64, _int]),
+    "rt_transpose": (_int, [_p, _p, _i64, _i64, _i64, _p, _i64]),
+    "rt_deim_greedy": (_int, [_p, _p, _i64, _i64, _i64, _int, _p, _p, _p]),
+    "rt_csr_spmm": (_int, [_p, _p, _p, _p, _i64, _p, _i64, _i64, _p, _i64]),
+    "rt_project_csr": (_int, [_p, _p, _p, _p, _i64, _p, _i64, _i64, _p]),
+    "rt_project_csr_batched": (_int, [_p, _p, _p, _p, _i64, _int, _i64, _i64, _p, _i64, _i64, _p]),
+    "rt_dense_solve_batched": (_int, [_p, _p, _p, _i64, _i64, _p]),
+    "rt_bench_mfma_f64": (_int, [_p, _int, C.POINTER(C.c_double)]),
+    "rt_bench_copy": (_int, [_p, _p, _p, _i64, _int, C.POINTER(C.c_double)]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class RomtimeHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (no GPU needed) and bind every declared symbol."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise RomtimeHipError(
+                f"{LIB_PATH} is missing: build it with `python -m romtime_amd.build` "
+                "(hipcc --offload-arch=gfx950). romtime_amd has no CPU fallback."
+            )
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the .so does not export it
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+        return lib
+
+
+class Context:
+    """One rt_ctx per (thread, device); the stream follows torch's current stream."""
+
+    _tls = threading.local()
+
+    def __init__(self, device: int):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RomtimeHipError("no MI355X visible: romtime_amd's hot path runs on the GPU only")
+        self.lib = load()
+        self.device = device
+        h = _p()
+        rc = self.lib.rt_ctx_create(C.byref(h), device)
+        if rc != RT_OK:
+            raise RomtimeHipError(f"rt_ctx_create(device={device}) failed with {rc}")
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.rt_ctx_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    @classmethod
+    def current(cls) -> "Context":
+        import torch
+
+        dev = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        cache = getattr(cls._tls, "cache", None)
+        if cache is None:
+            cache = cls._tls.cache = {}
+        ctx = cache.get(dev)
+        if ctx is None:
+            ctx = cache[dev] = cls(dev)
+        ctx.lib.rt_ctx_set_stream(ctx.handle, _p(torch.cuda.current_stream().cuda_stream))
+        return ctx
+
+    def check(self, rc: int, what: str) -> int:
+        if rc < 0:
+            msg = self.lib.rt_last_error(self.handle)
+            raise RomtimeHipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+        return rc
+
+    def launch_info(self):
+        buf = (_i64 * 3)()
+        self.lib.rt_last_launch_info(self.handle, buf)
+        return dict(grid=int(buf[0]), splits=int(buf[1]), tile=(int(buf[2]) // 1000, int(buf[2]) % 1000))

@@ -1,0 +1,245 @@
+// Context management and the thin C-ABI wrappers around the kernels.
+#include "common.h"
+
+#include <chrono>
+#include <new>
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+int grow(rt_ctx* ctx, void** buf, size_t* have, size_t bytes, void** out) {
+  if (bytes > *have) {
+    // kernels already enqueued may still use the old block
+    RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+    if (*buf) RT_HIP_CHECK(ctx, hipFree(*buf));
+    *buf = nullptr;
+    *have = 0;
+    const size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    RT_HIP_CHECK(ctx, hipMalloc(buf, want));
+    *have = want;
+  }
+  *out = *buf;
+  return RT_OK;
+}
+
+__global__ void gram_scale_kernel(double* __restrict__ G, int n, double* __restrict__ colnorm, int normalize,
+                                  int* status_flag) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)n * n) return;
+  const int i = (int)(idx / n), j = (int)(idx % n);
+  const double di = sqrt(G[(long)i * n + i]), dj = sqrt(G[(long)j * n + j]);
+  if (i == j) {
+    colnorm[i] = di;
+    if (status_flag && !(di > 0.0)) *status_flag = RT_WARN_ZERO_NORM;
+  }
+  // the diagonal is only read here; it is normalised by a second launch (gram_unit_diag_kernel)
+  if (normalize && i != j) G[idx] = G[idx] / (di * dj);
+}
+
+__global__ void gram_unit_diag_kernel(double* __restrict__ G, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const double d = G[(long)i * n + i];
+    G[(long)i * n + i] = d / (sqrt(d) * sqrt(d));
+  }
+}
+
+__global__ void transpose_kernel(const double* __restrict__ src, long rows, long cols, long ld_src,
+                                 double* __restrict__ dst, long ld_dst) {
+  __shared__ double tile[32][33];
+  const long r0 = (long)blockIdx.y * 32, c0 = (long)blockIdx.x * 32;
+  for (int rr = threadIdx.y; rr < 32; rr += blockDim.y) {
+    const long r = r0 + rr, c = c0 + threadIdx.x;
+    if (r < rows && c < cols) tile[rr][threadIdx.x] = src[r * ld_src + c];
+  }
+  __syncthreads();
+  for (int cc = threadIdx.y; cc < 32; cc += blockDim.y) {
+    const long c = c0 + cc, r = r0 + threadIdx.x;
+    if (c < cols && r < rows) dst[c * ld_dst + r] = tile[threadIdx.x][cc];
+  }
+}
+
+__global__ __launch_bounds__(256) void mfma_f64_peak_kernel(int iters, double* sink) {
+  d4 a0{0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
+  const double x = 1.0 + threadIdx.x * 1e-9, y = 1.0 - threadIdx.x * 1e-9;
+  for (int i = 0; i < iters; ++i) {
+    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, x, a1, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, a2, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, y, a3, 0, 0, 0);
+  }
+  const d4 s = a0 + a1 + a2 + a3;
+  if (s[0] + s[1] + s[2] + s[3] == -1.0) sink[0] = s[0];
+}
+
+__global__ __launch_bounds__(256) void copy_kernel(double4* __restrict__ dst, const double4* __restrict__ src, long n4) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+}
+
+}  // namespace
+
+int rt_scratch(rt_ctx* ctx, size_t bytes, void** out) { return grow(ctx, &ctx->scratch, &ctx->scratch_bytes, bytes, out); }
+int rt_scratch2(rt_ctx* ctx, size_t bytes, void** out) {
+  return grow(ctx, &ctx->scratch2, &ctx->scratch2_bytes, bytes, out);
+}
+
+extern "C" {
+
+int rt_version(void) { return 100; }
+
+int rt_ctx_create(rt_ctx** out, int device) {
+  if (!out) return RT_ERR_ARG;
+  *out = nullptr;
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return RT_ERR_HIP;
+  if (hipSetDevice(device) != hipSuccess) return RT_ERR_HIP;
+  rt_ctx* ctx = new (std::nothrow) rt_ctx();
+  if (!ctx) return RT_ERR_HIP;
+  ctx->device = device;
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+  *out = ctx;
+  return RT_OK;
+}
+
+void rt_ctx_destroy(rt_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->scratch) (void)hipFree(ctx->scratch);
+  if (ctx->scratch2) (void)hipFree(ctx->scratch2);
+  delete ctx;
+}
+
+int rt_ctx_set_stream(rt_ctx* ctx, void* hip_stream) {
+  if (!ctx) return RT_ERR_ARG;
+  ctx->stream = static_cast<hipStream_t>(hip_stream);
+  return RT_OK;
+}
+
+int rt_ctx_synchronize(rt_ctx* ctx) {
+  if (!ctx) return RT_ERR_ARG;
+  RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  return RT_OK;
+}
+
+const char* rt_last_error(rt_ctx* ctx) { return ctx ? ctx->err.c_str() : "null ctx"; }
+
+int rt_last_launch_info(rt_ctx* ctx, int64_t* info3) {
+  if (!ctx || !info3) return RT_ERR_ARG;
+  info3[0] = ctx->last_grid;
+  info3[1] = ctx->last_splits;
+  info3[2] = ctx->last_tile;
+  return RT_OK;
+}
+
+int rt_gram(rt_ctx* ctx, const double* X, int64_t n_rows, int64_t n_cols, int64_t ld, int layout, double* G) {
+  if (!ctx) return RT_ERR_ARG;
+  RT_ARG_CHECK(ctx, X && G && n_rows >= 1 && n_cols >= 1);
+  RT_ARG_CHECK(ctx, layout == RT_ROW_MAJOR || layout == RT_COL_MAJOR);
+  RT_ARG_CHECK(ctx, ld >= (layout == RT_ROW_MAJOR ? n_cols : n_rows));
+  const int64_t ks = (layout == RT_ROW_MAJOR) ? ld : 1, ms = (layout == RT_ROW_MAJOR) ? 1 : ld;
+  return rt_gemm_strided(ctx, X, ks, ms, X, ks, ms, n_rows, n_cols, n_cols, G, n_cols, 1, true, true);
+}
+
+int rt_gram_scale(rt_ctx* ctx, double* G, int64_t n, double* colnorm, int normalize, int* status_flag) {
+  if (!ctx) return RT_ERR_ARG;
+  RT_ARG_CHECK(ctx, G && colnorm && n >= 1 && n <= 46340);
+  if (status_flag) RT_HIP_CHECK(ctx, hipMemsetAsync(status_flag, 0, sizeof(int), ctx->stream));
+  const long total = (long)n * n;
+  hipLaunchKernelGGL(gram_scale_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, G, (int)n,
+                     colnorm, normalize, status_flag);
+  if (normalize)
+    hipLaunchKernelGGL(gram_unit_diag_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, G, (int)n);
+  RT_HIP_CHECK(ctx, hipGetLastError());
+  return RT_OK;
+}
+
+int rt_gemm_tn(rt_ctx* ctx, const double* A, int64_t lda, int a_layout, const double* B, int64_t ldb, int b_layout,
+               int64_t N, int64_t m, int64_t n, double* C, int64_t ldc) {
+  if (!ctx) return RT_ERR_ARG;
+  RT_ARG_CHECK(ctx, A && B && C && N >= 1 && m >= 1 && n >= 1 && ldc >= n);
+  RT_ARG_CHECK(ctx, (a_layout == RT_ROW_MAJOR || a_layout == RT_COL_MAJOR) &&
+                        (b_layout == RT_ROW_MAJOR || b_layout == RT_COL_MAJOR));
+  RT_ARG_CHECK(ctx, lda >= (a_layout == RT_ROW_MAJOR ? m : N) && ldb >= (b_layout == RT_ROW_MAJOR ? n : N));
+  const int64_t a_ks = (a_layout == RT_ROW_MAJOR) ? lda : 1, a_ms = (a_layout == RT_ROW_MAJOR) ? 1 : lda;
+  const int64_t b_ks = (b_layout == RT_ROW_MAJOR) ? ldb : 1, b_ns = (b_layout == RT_ROW_MAJOR) ? 1 : ldb;
+  const bool sym = (A == B) && (m == n) && (lda == ldb) && (a_layout == b_layout);
+  return rt_gemm_strided(ctx, A, a_ks, a_ms, B, b_ks, b_ns, N, m, n, C, ldc, 1, sym, true);
+}
+
+int rt_gemm_nn(rt_ctx* ctx, const double* X, int64_t ldx, int x_layout, const double* T, int64_t ldt, int64_t N,
+               int64_t n, int64_t k, double* Y, int64_t ldy, int y_layout) {
+  if (!ctx) return RT_ERR_ARG;
+  RT_ARG_CHECK(ctx, X && T && Y && N >= 1 && n >= 1 && k >= 1 && ldt >= k);
+  RT_ARG_CHECK(ctx, (x_layout == RT_ROW_MAJOR || x_layout == RT_COL_MAJOR) &&
+                        (y_layout == RT_ROW_MAJOR || y_layout == RT_COL_MAJOR));
+  RT_ARG_CHECK(ctx, ldx >= (x_layout == RT_ROW_MAJOR ? n : N) && ldy >= (y_layout == RT_ROW_MAJOR ? k : N));
+  // contraction over the n columns of X: A(c, i) = X[i][c]
+  const int64_t a_ks = (x_layout == RT_ROW_MAJOR) ? 1 : ldx, a_ms = (x_layout == RT_ROW_MAJOR) ? ldx : 1;
+  const int64_t c_rs = (y_layout == RT_ROW_MAJOR) ? ldy : 1, c_cs = (y_layout == RT_ROW_MAJOR) ? 1 : ldy;
+  return rt_gemm_strided(ctx, X, a_ks, a_ms, T, ldt, 1, n, N, k, Y, c_rs, c_cs, false, false);
+}
+
+int rt_transpose(rt_ctx* ctx, const double* src, int64_t rows, int64_t cols, int64_t ld_src, double* dst,
+                 int64_t ld_dst) {
+  if (!ctx) return RT_ERR_ARG;
+  RT_ARG_CHECK(ctx, src && dst && rows >= 1 && cols >= 1 && ld_src >= cols && ld_dst >= rows);
+  dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
+  RT_ARG_CHECK(ctx, grid.y <= 65535 * 32);
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(32, 8), 0, ctx->stream, src, (long)rows, (long)cols, (long)ld_src,
+                     dst, (long)ld_dst);
+  RT_HIP_CHECK(ctx, hipGetLastError());
+  return RT_OK;
+}
+
+int rt_bench_mfma_f64(rt_ctx* ctx, int iters, double* tflops) {
+  if (!ctx || !tflops || iters < 1) return RT_ERR_ARG;
+  void* sink = nullptr;
+  int rc = rt_scratch(ctx, 256, &sink);
+  if (rc != RT_OK) return rc;
+  const int grid = ctx->num_cus * 2;  // 2 x 4 waves per CU = 2 waves per SIMD
+  hipEvent_t e0, e1;
+  RT_HIP_CHECK(ctx, hipEventCreate(&e0));
+  RT_HIP_CHECK(ctx, hipEventCreate(&e1));
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(grid), dim3(256), 0, ctx->stream, iters / 10 + 1,
+                     static_cast<double*>(sink));
+  RT_HIP_CHECK(ctx, hipEventRecord(e0, ctx->stream));
+  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(grid), dim3(256), 0, ctx->stream, iters, static_cast<double*>(sink));
+  RT_HIP_CHECK(ctx, hipEventRecord(e1, ctx->stream));
+  RT_HIP_CHECK(ctx, hipEventSynchronize(e1));
+  float ms = 0.f;
+  RT_HIP_CHECK(ctx, hipEventElapsedTime(&ms, e0, e1));
+  const double flops = (double)grid * 4 /*waves*/ * (double)iters * 4 /*mfma per iter*/ * 2048.0;
+  *tflops = flops / (ms * 1e-3) / 1e12;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return RT_OK;
+}
+
+int rt_bench_copy(rt_ctx* ctx, void* dst, const void* src, int64_t bytes, int reps, double* gbps) {
+  if (!ctx || !dst || !src || !gbps || bytes < 32 || reps < 1) return RT_ERR_ARG;
+  const long n4 = bytes / 32;
+  hipEvent_t e0, e1;
+  RT_HIP_CHECK(ctx, hipEventCreate(&e0));
+  RT_HIP_CHECK(ctx, hipEventCreate(&e1));
+  const int grid = ctx->num_cus * 8;
+  hipLaunchKernelGGL(copy_kernel, dim3(grid), dim3(256), 0, ctx->stream, static_cast<double4*>(dst),
+                     static_cast<const double4*>(src), n4);
+  RT_HIP_CHECK(ctx, hipEventRecord(e0, ctx->stream));
+  for (int i = 0; i < reps; ++i)
+    hipLaunchKernelGGL(copy_kernel, dim3(grid), dim3(256), 0, ctx->stream, static_cast<double4*>(dst),
+                       static_cast<const double4*>(src), n4);
+  RT_HIP_CHECK(ctx, hipEventRecord(e1, ctx->stream));
+  RT_HIP_CHECK(ctx, hipEventSynchronize(e1));
+  float ms = 0.f;
+  RT_HIP_CHECK(ctx, hipEventElapsedTime(&ms, e0, e1));
+  *gbps = 2.0 * (double)(n4 * 32) * reps / (ms * 1e-3) / 1e9;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,50 @@
+// Shared declarations for libromtime_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "../../include/romtime_hip.h"
+
+struct rt_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  void* scratch = nullptr;   // leaf arena: GEMM split slabs
+  size_t scratch_bytes = 0;
+  void* scratch2 = nullptr;  // composite arena: workspaces of ops that call the GEMM (AV, DEIM state)
+  size_t scratch2_bytes = 0;
+  int num_cus = 256;
+  std::string err;
+  int64_t last_grid = 0, last_splits = 0, last_tile = 0;
+};
+
+#define RT_HIP_CHECK(ctx, expr)                                                              \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) {                                                                  \
+      (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                        \
+      return RT_ERR_HIP;                                                                     \
+    }                                                                                        \
+  } while (0)
+
+#define RT_ARG_CHECK(ctx, cond)                                                              \
+  do {                                                                                       \
+    if (!(cond)) {                                                                           \
+      (ctx)->err = std::string("bad argument: ") + #cond;                                    \
+      return RT_ERR_ARG;                                                                     \
+    }                                                                                        \
+  } while (0)
+
+// Returns a device pointer to at least `bytes` of scratch owned by the ctx (256-B aligned).
+int rt_scratch(rt_ctx* ctx, size_t bytes, void** out);
+int rt_scratch2(rt_ctx* ctx, size_t bytes, void** out);
+
+// Generic strided GEMM on the f64 matrix cores:  C(i,j) = sum_k A(k,i) * B(k,j).
+//   A(k,i) at A[k*a_ks + i*a_ms]  (exactly one of a_ks / a_ms is 1, or M == 1)
+//   B(k,j) at B[k*b_ks + j*b_ns]
+//   C(i,j) at C[i*c_rs + j*c_cs]
+// `symmetric`: A == B, M == Nn; only tiles on/above the diagonal are computed, then mirrored.
+// `allow_split`: contraction may be split over workgroups (deterministic slab reduction).
+int rt_gemm_strided(rt_ctx* ctx, const double* A, int64_t a_ks, int64_t a_ms, const double* B, int64_t b_ks,
+                    int64_t b_ns, int64_t K, int64_t M, int64_t Nn, double* C, int64_t c_rs, int64_t c_cs,
+                    bool symmetric, bool allow_split);

@@ -1,0 +1,198 @@
+"""Device operators of the POD / (M)DEIM / reduced-solve path (thin wrappers over the C ABI).
+
+Inputs are float64 CUDA ``torch.Tensor``s (torch is the allocator / stream provider only);
+``to_device`` moves NumPy data over PCIe preserving its C/F memory order so that no host
+transpose is ever made.  Every function raises if the HIP library or the GPU is absent.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import COL_MAJOR, ROW_MAJOR, Context, RomtimeHipError
+
+_p = C.c_void_p
+
+
+def _ptr(t):
+    return _p(t.data_ptr()) if t is not None else _p(None)
+
+
+def to_device(a, device=None) -> torch.Tensor:
+    """NumPy (or tensor) -> float64 CUDA tensor with the same logical shape and memory order."""
+    if isinstance(a, torch.Tensor):
+        t = a.to(dtype=torch.float64)
+        return t.cuda(device) if not t.is_cuda else t
+    a = np.asarray(a, dtype=np.float64)
+    if a.ndim == 2 and a.flags.f_contiguous and not a.flags.c_contiguous:
+        return torch.from_numpy(np.ascontiguousarray(a.T)).cuda(device).T
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda(device)
+
+
+def to_device_index(a, device=None) -> torch.Tensor:
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.int64))).cuda(device)
+
+
+def _layout(t: torch.Tensor):
+    """(tensor, ld, layout) for a 2-D float64 CUDA tensor; copies only if it has no unit stride."""
+    if t.dtype != torch.float64 or not t.is_cuda or t.dim() != 2:
+        raise RomtimeHipError("expected a 2-D float64 CUDA tensor")
+    r, c = t.shape
+    s0, s1 = t.stride()
+    if s1 == 1 and (s0 >= c or r == 1):
+        return t, max(s0, c), ROW_MAJOR
+    if s0 == 1 and (s1 >= r or c == 1):
+        return t, max(s1, r), COL_MAJOR
+    t = t.contiguous()
+    return t, c, ROW_MAJOR
+
+
+def gram(X: torch.Tensor) -> torch.Tensor:
+    """G = X^T X (n x n). rt_gram."""
+    ctx = Context.current()
+    X, ld, lay = _layout(X)
+    N, n = X.shape
+    G = torch.empty((n, n), dtype=torch.float64, device=X.device)
+    ctx.check(ctx.lib.rt_gram(ctx.handle, _ptr(X), N, n, ld, lay, _ptr(G)), "rt_gram")
+    return G
+
+
+def gram_scale(G: torch.Tensor, normalize: bool):
+    """In place: returns (colnorm, status_flag tensor). rt_gram_scale."""
+    ctx = Context.current()
+    n = G.shape[0]
+    assert G.is_contiguous() and G.shape == (n, n)
+    colnorm = torch.empty(n, dtype=torch.float64, device=G.device)
+    flag = torch.zeros(1, dtype=torch.int32, device=G.device)
+    ctx.check(ctx.lib.rt_gram_scale(ctx.handle, _ptr(G), n, _ptr(colnorm), int(bool(normalize)), _ptr(flag)),
+              "rt_gram_scale")
+    return colnorm, flag
+
+
+def gemm_tn(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
+    """C = A^T B with the contraction over the rows (DoFs). rt_gemm_tn."""
+    ctx = Context.current()
+    if B.dim() == 1:
+        return gemm_tn(A, B.unsqueeze(1)).squeeze(1)
+    same = A is B
+    A, lda, la = _layout(A)
+    if same:
+        B, ldb, lb = A, lda, la
+    else:
+        B, ldb, lb = _layout(B)
+    N, m = A.shape
+    N2, n = B.shape
+    if N != N2:
+        raise RomtimeHipError(f"gemm_tn: row counts differ ({N} vs {N2})")
+    Cm = torch.empty((m, n), dtype=torch.float64, device=A.device)
+    ctx.check(ctx.lib.rt_gemm_tn(ctx.handle, _ptr(A), lda, la, _ptr(B), ldb, lb, N, m, n, _ptr(Cm), n), "rt_gemm_tn")
+    return Cm
+
+
+def gemm_nn(X: torch.Tensor, T: torch.Tensor) -> torch.Tensor:
+    """Y = X T (N x k, row-major). rt_gemm_nn."""
+    ctx = Context.current()
+    if T.dim() == 1:
+        return gemm_nn(X, T.unsqueeze(1)).squeeze(1)
+    X, ldx, lx = _layout(X)
+    T = T.contiguous()
+    N, n = X.shape
+    n2, k = T.shape
+    if n != n2:
+        raise RomtimeHipError(f"gemm_nn: inner dimensions differ ({n} vs {n2})")
+    Y = torch.empty((N, k), dtype=torch.float64, device=X.device)
+    ctx.check(ctx.lib.rt_gemm_nn(ctx.handle, _ptr(X), ldx, lx, _ptr(T), k, N, n, k, _ptr(Y), k, ROW_MAJOR), "rt_gemm_nn")
+    return Y
+
+
+def deim_greedy(Phi: torch.Tensor, want_margin: bool = True):
+    """(idx int64[m], PT_U [m,m], margin [m] or None), all on the device. rt_deim_greedy."""
+    ctx = Context.current()
+    Phi, ld, lay = _layout(Phi)
+    N, m = Phi.shape
+    idx = torch.empty(m, dtype=torch.int64, device=Phi.device)
+    PT_U = torch.empty((m, m), dtype=torch.float64, device=Phi.device)
+    margin = torch.empty(m, dtype=torch.float64, device=Phi.device) if want_margin else None
+    ctx.check(ctx.lib.rt_deim_greedy(ctx.handle, _ptr(Phi), N, m, ld, lay, _ptr(idx), _ptr(PT_U), _ptr(margin)),
+              "rt_deim_greedy")
+    return idx, PT_U, margin
+
+
+def csr_spmm(indptr, indices, data, V: torch.Tensor) -> torch.Tensor:
+    ctx = Context.current()
+    V = V.contiguous()
+    N = indptr.numel() - 1
+    r = V.shape[1]
+    Y = torch.empty((N, r), dtype=torch.float64, device=V.device)
+    ctx.check(ctx.lib.rt_csr_spmm(ctx.handle, _ptr(indptr), _ptr(indices), _ptr(data), N, _ptr(V), r, r, _ptr(Y), r),
+              "rt_csr_spmm")
+    return Y
+
+
+def project_csr(indptr, indices, data, V: torch.Tensor) -> torch.Tensor:
+    """A_N = V^T (A V). rt_project_csr."""
+    ctx = Context.current()
+    V = V.contiguous()
+    N = indptr.numel() - 1
+    if V.shape[0] != N:
+        raise RomtimeHipError("project_csr: V has the wrong number of rows")
+    r = V.shape[1]
+    AN = torch.empty((r, r), dtype=torch.float64, device=V.device)
+    ctx.check(ctx.lib.rt_project_csr(ctx.handle, _ptr(indptr), _ptr(indices), _ptr(data), N, _ptr(V), r, r, _ptr(AN)),
+              "rt_project_csr")
+    return AN
+
+
+def project_csr_batched(indptr, indices, data_batch: torch.Tensor, V: torch.Tensor) -> torch.Tensor:
+    """data_batch is (nnz x B) (modes as columns, either memory order) -> (B, r, r)."""
+    ctx = Context.current()
+    V = V.contiguous()
+    data_batch, ld, lay = _layout(data_batch)
+    nnz, B = data_batch.shape
+    N = indptr.numel() - 1
+    r = V.shape[1]
+    AN = torch.empty((B, r, r), dtype=torch.float64, device=V.device)
+    ctx.check(ctx.lib.rt_project_csr_batched(ctx.handle, _ptr(indptr), _ptr(indices), _ptr(data_batch), ld, lay, B, N,
+                                             _ptr(V), r, r, _ptr(AN)), "rt_project_csr_batched")
+    return AN
+
+
+def dense_solve(K: torch.Tensor, b: torch.Tensor):
+    """Solve K x = b (K: [r,r] or [B,r,r]; b: [r] or [B,r]). Returns (x, info). Inputs are not modified."""
+    ctx = Context.current()
+    single = K.dim() == 2
+    Kw = K.reshape(-1, K.shape[-2], K.shape[-1]).contiguous().clone()
+    bw = b.reshape(Kw.shape[0], -1).contiguous().clone()
+    B, r, _ = Kw.shape
+    info = torch.zeros(B, dtype=torch.int32, device=K.device)
+    ctx.check(ctx.lib.rt_dense_solve_batched(ctx.handle, _ptr(Kw), _ptr(bw), r, B, _ptr(info)),
+              "rt_dense_solve_batched")
+    return (bw[0] if single else bw), info
+
+
+def transpose(src: torch.Tensor) -> torch.Tensor:
+    ctx = Context.current()
+    src = src.contiguous()
+    rows, cols = src.shape
+    dst = torch.empty((cols, rows), dtype=torch.float64, device=src.device)
+    ctx.check(ctx.lib.rt_transpose(ctx.handle, _ptr(src), rows, cols, cols, _ptr(dst), rows), "rt_transpose")
+    return dst
+
+
+def bench_mfma_f64(iters: int = 20000) -> float:
+    ctx = Context.current()
+    out = C.c_double()
+    ctx.check(ctx.lib.rt_bench_mfma_f64(ctx.handle, iters, C.byref(out)), "rt_bench_mfma_f64")
+    return out.value
+
+
+def bench_copy(nbytes: int = 1 << 30, reps: int = 10) -> float:
+    ctx = Context.current()
+    src = torch.empty(nbytes // 8, dtype=torch.float64, device="cuda").normal_()
+    dst = torch.empty_like(src)
+    out = C.c_double()
+    ctx.check(ctx.lib.rt_bench_copy(ctx.handle, _ptr(dst), _ptr(src), nbytes, reps, C.byref(out)), "rt_bench_copy")
+    return out.value

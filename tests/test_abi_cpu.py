@@ -1,0 +1,32 @@
+"""CPU-side checks of the drop-in boundary: the library loads and exports what the header declares."""
+import os
+import re
+
+from romtime_amd import _lib
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(REPO, "include", "romtime_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return set(re.findall(r"\b(rt_[a-z0-9_]+)\s*\(", text))
+
+
+def test_library_loads_and_exports_every_declared_symbol():
+    lib = _lib.load()
+    declared = _declared()
+    assert declared, "no declarations parsed"
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in include/romtime_hip.h but not exported"
+    assert lib.rt_version() >= 100
+
+
+def test_binding_table_matches_header():
+    assert set(_lib.SIGNATURES) == _declared()
+
+
+def test_header_cites_reference_for_each_hot_entry_point():
+    text = open(os.path.join(REPO, "include", "romtime_hip.h")).read()
+    for needle in ("pod.py", "deim.py:517-561", "utils.py:96-113", "mdeim.py:153-192", "rom.py"):
+        assert needle in text

@@ -1,0 +1,181 @@
+"""Parity of the HIP kernels (through the C ABI) with the CPU oracle / golden vectors."""
+import numpy as np
+import pytest
+import torch
+from scipy.sparse import csr_matrix
+
+from oracle import romtime_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from romtime_amd import ops as _ops
+
+    return _ops
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
+
+
+@pytest.mark.parametrize("N,n", [(1, 1), (7, 3), (64, 16), (1000, 64), (777, 33), (4099, 130), (20000, 256), (3000, 512)])
+@pytest.mark.parametrize("order", ["C", "F"])
+def test_gram(ops, N, n, order):
+    rng = np.random.RandomState(N + n)
+    X = rng.standard_normal((N, n))
+    X = np.asfortranarray(X) if order == "F" else np.ascontiguousarray(X)
+    G = ops.gram(ops.to_device(X)).cpu().numpy()
+    ref = X.T @ X
+    assert _rel(G, ref) < 5e-14
+    np.testing.assert_array_equal(G, G.T)  # exactly symmetric by construction
+
+
+def test_mfma_layout_asymmetric(ops):
+    """A = I-like selector against an asymmetric B catches swapped C/D row/col maps."""
+    N, m, n = 64, 48, 80
+    A = np.zeros((N, m))
+    A[np.arange(m), np.arange(m)] = 1.0
+    B = np.arange(N * n, dtype=float).reshape(N, n) + 0.5
+    C = ops.gemm_tn(ops.to_device(A), ops.to_device(B)).cpu().numpy()
+    np.testing.assert_array_equal(C, B[:m, :])
+
+
+@pytest.mark.parametrize("N,m,n", [(500, 10, 7), (4096, 80, 80), (10001, 80, 1), (3333, 1, 5), (2048, 96, 200), (5000, 130, 40)])
+@pytest.mark.parametrize("oa,ob", [("C", "C"), ("F", "C"), ("C", "F"), ("F", "F")])
+def test_gemm_tn(ops, N, m, n, oa, ob):
+    rng = np.random.RandomState(N + m + n)
+    A = rng.standard_normal((N, m))
+    B = rng.standard_normal((N, n))
+    A = np.asfortranarray(A) if oa == "F" else A
+    B = np.asfortranarray(B) if ob == "F" else B
+    C = ops.gemm_tn(ops.to_device(A), ops.to_device(B)).cpu().numpy()
+    assert _rel(C, A.T @ B) < 5e-14
+
+
+@pytest.mark.parametrize("N,n,k", [(100, 8, 3), (5000, 64, 10), (4097, 256, 40), (3000, 33, 1), (2500, 512, 80), (999, 130, 130)])
+@pytest.mark.parametrize("order", ["C", "F"])
+def test_gemm_nn(ops, N, n, k, order):
+    rng = np.random.RandomState(N + n + k)
+    X = rng.standard_normal((N, n))
+    X = np.asfortranarray(X) if order == "F" else X
+    T = rng.standard_normal((n, k))
+    Y = ops.gemm_nn(ops.to_device(X), ops.to_device(T)).cpu().numpy()
+    assert _rel(Y, X @ T) < 5e-14
+
+
+def test_gram_scale(ops):
+    rng = np.random.RandomState(5)
+    X = rng.standard_normal((400, 24)) * 10.0 ** rng.uniform(-3, 3, 24)
+    G = ops.gram(ops.to_device(X))
+    cn, flag = ops.gram_scale(G, True)
+    l2 = np.linalg.norm(X, axis=0)
+    np.testing.assert_allclose(cn.cpu().numpy(), l2, rtol=1e-14)
+    Xn = X / l2
+    np.testing.assert_allclose(G.cpu().numpy(), Xn.T @ Xn, rtol=0, atol=1e-14)
+    assert int(flag.item()) == 0
+    Z = X.copy()
+    Z[:, 3] = 0.0
+    G = ops.gram(ops.to_device(Z))
+    cn, flag = ops.gram_scale(G, True)
+    assert int(flag.item()) == 1 and np.isnan(G.cpu().numpy()[3, 3])
+
+
+def test_greedy_golden(ops, golden_deim):
+    g = golden_deim
+    for name in g["names"]:
+        B = g[f"basis__{name}"]
+        for arr in (np.ascontiguousarray(B), np.asfortranarray(B)):
+            idx, PT_U, margin = ops.deim_greedy(ops.to_device(arr))
+            idx = idx.cpu().numpy()
+            ref = g[f"dofs__{name}"]
+            mref = g[f"margin__{name}"]
+            # bit-exact wherever the step is not a numerical tie; on exact ties the first index wins
+            assert list(idx) == list(ref), (name, idx, ref, mref)
+            np.testing.assert_array_equal(PT_U.cpu().numpy(), g[f"PT_U__{name}"])
+            np.testing.assert_allclose(margin.cpu().numpy(), mref, rtol=1e-6, atol=1e-11)
+
+
+@pytest.mark.parametrize("N,m", [(5000, 40), (20011, 120), (1500, 7)])
+def test_greedy_random(ops, N, m):
+    rng = np.random.RandomState(m)
+    B, _ = np.linalg.qr(rng.standard_normal((N, m)))
+    dofs, PT_U, margin = oracle.deim_greedy(B)
+    idx, PT_U_d, margin_d = ops.deim_greedy(ops.to_device(np.asfortranarray(B)))
+    assert list(idx.cpu().numpy()) == list(dofs)
+    np.testing.assert_array_equal(PT_U_d.cpu().numpy(), PT_U)
+    idx2, _, _ = ops.deim_greedy(ops.to_device(np.ascontiguousarray(B)))
+    assert list(idx2.cpu().numpy()) == list(dofs)
+
+
+def _penta(N, rng):
+    offs = [-2, -1, 0, 1, 2]
+    rows, cols = [], []
+    for o in offs:
+        i = np.arange(max(0, -o), min(N, N - o))
+        rows.append(i)
+        cols.append(i + o)
+    rows, cols = np.concatenate(rows), np.concatenate(cols)
+    A = csr_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=(N, N))
+    A.sort_indices()
+    return A
+
+
+@pytest.mark.parametrize("N,r", [(300, 8), (5000, 80), (2048, 33)])
+def test_project_csr(ops, N, r):
+    rng = np.random.RandomState(N)
+    A = _penta(N, rng)
+    V, _ = np.linalg.qr(rng.standard_normal((N, r)))
+    ip, ix = ops.to_device_index(A.indptr), ops.to_device_index(A.indices)
+    Vd = ops.to_device(V)
+    Y = ops.csr_spmm(ip, ix, ops.to_device(A.data), Vd).cpu().numpy()
+    assert _rel(Y, A.dot(V)) < 1e-14
+    AN = ops.project_csr(ip, ix, ops.to_device(A.data), Vd).cpu().numpy()
+    assert _rel(AN, oracle.project_csr(A, V)) < 1e-13
+
+
+def test_project_csr_golden_and_batched(ops, golden_deim):
+    g = golden_deim
+    ip, ix = ops.to_device_index(g["csr_indptr"]), ops.to_device_index(g["csr_indices"])
+    V = ops.to_device(g["mdeim_V"])
+    AN = ops.project_csr(ip, ix, ops.to_device(g["csr_data"]), V).cpu().numpy()
+    np.testing.assert_allclose(AN, g["project_csr"], rtol=0, atol=1e-13)
+    # MDEIM.project_basis fixture: (nnz x m) modes -> (r*r x m)
+    rows, cols = g["mdeim_rows"], g["mdeim_cols"]
+    N = V.shape[0]
+    pat = csr_matrix((np.ones(rows.size), (rows, cols)), shape=(N, N))
+    pat.sort_indices()
+    ipp, ixp = ops.to_device_index(pat.indptr), ops.to_device_index(pat.indices)
+    for arr in (np.ascontiguousarray(g["mdeim_basis_fom"]), np.asfortranarray(g["mdeim_basis_fom"])):
+        ANb = ops.project_csr_batched(ipp, ixp, ops.to_device(arr), V).cpu().numpy()
+        got = ANb.reshape(ANb.shape[0], -1).T
+        np.testing.assert_allclose(got, g["mdeim_basis_rom"], rtol=0, atol=1e-13)
+
+
+@pytest.mark.parametrize("r,B", [(1, 1), (5, 3), (24, 2), (80, 32), (120, 4), (128, 1)])
+def test_dense_solve(ops, r, B):
+    rng = np.random.RandomState(r)
+    K = rng.standard_normal((B, r, r)) + np.eye(r) * 0.1
+    b = rng.standard_normal((B, r))
+    x, info = ops.dense_solve(ops.to_device(K), ops.to_device(b))
+    ref = np.linalg.solve(K, b[..., None])[..., 0]
+    res = np.abs(np.einsum("bij,bj->bi", K, x.cpu().numpy()) - b).max()
+    assert res < 1e-10
+    np.testing.assert_allclose(x.cpu().numpy(), ref, rtol=1e-8, atol=1e-10)
+    assert int(info.abs().sum().item()) == 0
+
+
+def test_dense_solve_singular_flag(ops):
+    K = np.zeros((1, 4, 4))
+    x, info = ops.dense_solve(ops.to_device(K), ops.to_device(np.ones((1, 4))))
+    assert int(info[0].item()) == 2
+
+
+def test_unsupported_sizes_fail_loudly(ops):
+    from romtime_amd._lib import RomtimeHipError
+
+    with pytest.raises(RomtimeHipError):
+        ops.dense_solve(torch.eye(200, dtype=torch.float64, device="cuda"), torch.ones(200, dtype=torch.float64, device="cuda"))
+    with pytest.raises(RomtimeHipError):
+        ops.gemm_tn(torch.ones((4, 2), dtype=torch.float64, device="cuda"), torch.ones((5, 2), dtype=torch.float64, device="cuda"))
