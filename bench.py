@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Headline benchmark: POD build throughput (snapshot-DoF/s) on the BASELINE.json workload.
+
+Workload (BASELINE.json configs[2], the shape the metric and the north-star target are quoted
+on; 4.1 GB, fits one GPU): synthetic snapshot matrix N_h = 1e6 x n_s = 512 (float64, prescribed
+singular-value decay 10^(-8 i/511)), r = 40 POD modes, orth(normalize=True, num=40).
+One "step" = one full orth-equivalent on snapshots already resident in HBM:
+    Gram (FP64 MFMA) -> [all-reduce] -> normalise -> n x n eigensolve -> back-projection.
+With --gpus N the rows are sharded over the N ranks (strong scaling: the global matrix is the
+same for N = 1, 2, 4, 8) and the Gram matrix is all-reduced over RCCL.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` for the dominant
+kernel (the Gram MFMA kernel, timed with HIP events on its own stream inside the timed region)
+and `cpu_baseline` (the NumPy/SciPy oracle -- the reference's exact library calls -- on a bounded
+row sample, rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+N_H, N_S, R_MODES = 1_000_000, 512, 40
+CHUNK_ROWS = 125_000          # the global matrix is generated in 8 fixed chunks (seed = base + chunk)
+SEED = 20260104 + 3
+FP64_MFMA_PEAK_TFLOPS = 78.6  # MI355X FP64 matrix peak (AMD spec) -- the guide lists no f64 row
+HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def spectrum(n):
+    return 10.0 ** (-8.0 * np.arange(n) / (n - 1))
+
+
+def mixing_matrix(n, device):
+    """diag(sigma) V0^T with V0 a fixed orthogonal matrix (same on every rank)."""
+    g = torch.Generator(device="cpu").manual_seed(SEED)
+    V0, _ = torch.linalg.qr(torch.randn((n, n), dtype=torch.float64, generator=g))
+    return (torch.from_numpy(spectrum(n))[:, None] * V0.T).to(device)
+
+
+def make_chunk(c, rows, n, mix, device):
+    """Rows [c*CHUNK, c*CHUNK + rows) of the global snapshot matrix: (Z / sqrt(N_H)) diag(sigma) V0^T."""
+    g = torch.Generator(device=device).manual_seed(SEED + 1 + c)
+    Z = torch.randn((rows, n), dtype=torch.float64, device=device, generator=g)
+    return (Z @ mix) * (1.0 / np.sqrt(N_H))
+
+
+def build_local_matrix(rank, world, n_h, n, device):
+    mix = mixing_matrix(n, device)
+    n_chunks = (n_h + CHUNK_ROWS - 1) // CHUNK_ROWS
+    per_rank = (n_chunks + world - 1) // world
+    parts = []
+    for c in range(rank * per_rank, min(n_chunks, (rank + 1) * per_rank)):
+        rows = min(CHUNK_ROWS, n_h - c * CHUNK_ROWS)
+        parts.append(make_chunk(c, rows, n, mix, device))
+    X = torch.cat(parts, dim=0) if len(parts) > 1 else parts[0]
+    return X.contiguous()
+
+
+def cpu_baseline(n, r, sample_rows):
+    """The oracle's orth (column norms + divide + dgesvd + energy + truncation, pod.py:31-57) on the
+    first `sample_rows` rows of the same synthetic matrix, all host cores."""
+    from oracle import romtime_oracle as oracle
+
+    mix = mixing_matrix(n, "cpu")
+    X = make_chunk(0, sample_rows, n, mix, "cpu").numpy()
+    t0 = time.perf_counter()
+    Q, s, energy = oracle.orth(X, num=r, normalize=True)
+    dt = time.perf_counter() - t0
+    return dict(value=sample_rows * n / dt, unit="snapshot-DoF/s", cores=os.cpu_count(), kind="port",
+                sample=f"oracle.orth (scipy dgesvd) on the first {sample_rows} x {n} rows of the workload, "
+                       f"{dt:.2f} s, numpy {np.__version__}")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--rows", type=int, default=N_H)
+    ap.add_argument("--cols", type=int, default=N_S)
+    ap.add_argument("--modes", type=int, default=R_MODES)
+    ap.add_argument("--cpu-sample-rows", type=int, default=40_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: romtime_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        group = dist.group.WORLD
+
+    from romtime_amd import pod
+    from romtime_amd._lib import Context
+
+    n_h, n, r = args.rows, args.cols, args.modes
+    X = build_local_matrix(rank, world, n_h, n, device)
+    n_local = X.shape[0]
+    ctx = Context.current()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step():
+        return pod.pod_device(X, num=r, normalize=True, group=group)
+
+    for _ in range(args.warmup):
+        out = step()
+    ctx.set_profile(True)
+    gram_ms = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+        # the first profiled GEMM of a step is the Gram kernel; read its event pair after the step
+        gram_ms.append(pod.LAST_TIMINGS.get("gram_kernel_ms", float("nan")))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ctx.set_profile(False)
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        value = n_h * n * args.steps / elapsed
+        k_ms = float(np.nanmean(gram_ms))
+        alg_flops = n_local * n * (n + 1)           # symmetric Gram: N n (n+1) flops
+        alg_bytes = 8 * (n_local * n + n * n)       # read X once + write G
+        achieved = alg_flops / (k_ms * 1e-3) / 1e12
+        roofline = dict(bound="mfma", achieved=achieved, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=achieved / FP64_MFMA_PEAK_TFLOPS, traffic=None,
+                        kernel="gemm_f64_mfma_kernel (Gram, symmetric tiles)", kernel_ms=k_ms,
+                        hbm_frac=alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        note="FP64 Gram at n=512 is 64 flop/B: matrix-core bound, not HBM bound")
+        line = {
+            "metric": "snapshot-DoF/s for POD build",
+            "value": value,
+            "unit": "snapshot-DoF/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"pod_{n_h}x{n}_r{r}_normalize", "n_h": n_h, "n_snapshots": n, "modes": r,
+                       "rows_per_gpu": n_local, "passes": out["passes"], "parallelism": f"row-sharded x{world}"},
+            "stage_ms": {k: round(v, 4) for k, v in pod.LAST_TIMINGS.items()},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(n, r, min(args.cpu_sample_rows, n_h))
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

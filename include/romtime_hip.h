@@ -47,6 +47,12 @@ const char* rt_last_error(rt_ctx* ctx);
 /* dispatch statistics of the most recent GEMM-class launch: [0]=grid, [1]=splits, [2]=tile */
 int rt_last_launch_info(rt_ctx* ctx, int64_t* info3);
 
+/* Measurement: when on, every GEMM-class call brackets its main MFMA kernel (not the slab
+ * reduction) with hipEvents on the ctx stream; rt_last_gemm_ms synchronises on the second event
+ * and returns that kernel's duration in milliseconds. */
+int rt_ctx_set_profile(rt_ctx* ctx, int on);
+int rt_last_gemm_ms(rt_ctx* ctx, double* ms);
+
 /* ---- POD (src/romtime/rom/pod.py:7-62) ------------------------------------------------ */
 
 /* G = X^T X (n_cols x n_cols, row-major, full symmetric).  X is n_rows x n_cols with
@@ -114,6 +120,14 @@ int rt_project_csr_batched(rt_ctx* ctx, const int64_t* indptr, const int64_t* in
  * K (B x r x r row-major) is overwritten with its factors, rhs (B x r) with x.
  * info (B device ints, may be NULL): 0, or RT_WARN_SINGULAR. r <= 128. */
 int rt_dense_solve_batched(rt_ctx* ctx, double* K, double* rhs, int64_t r, int64_t B, int* info);
+
+/* ---- host-side small dense step --------------------------------------------------------- */
+/* Cyclic two-sided Jacobi eigen-decomposition of a symmetric PSD n x n HOST matrix A (row-major,
+ * destroyed): A = W diag(lam) W^T, lam descending, eigenvectors in the columns of W (row-major).
+ * Relative stopping rule |a_pq| <= eps sqrt(a_pp a_qq): small eigenvalues of a graded matrix come
+ * out to high relative accuracy (what dgesvd delivers on the snapshots themselves, pod.py:38).
+ * HOST pointers; no ctx; used on the second-pass Gram matrix of rt_gram. */
+int rt_host_jacobi_eigh(double* A, int64_t n, double* W, double* lam, int max_sweeps, int* sweeps_done);
 
 /* ---- measurement helpers (not part of the reference surface) ------------------------------ */
 /* Runs `iters` back-to-back v_mfma_f64_16x16x4_f64 per wave on a full-chip grid and returns

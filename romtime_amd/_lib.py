@@ -30,6 +30,8 @@ SIGNATURES = {
     "rt_ctx_synchronize": (_int, [_p]),
     "rt_last_error": (C.c_char_p, [_p]),
     "rt_last_launch_info": (_int, [_p, C.POINTER(_i64)]),
+    "rt_ctx_set_profile": (_int, [_p, _int]),
+    "rt_last_gemm_ms": (_int, [_p, C.POINTER(C.c_double)]),
     "rt_gram": (_int, [_p, _p, _i64, _i64, _i64, _int, _p]),
     "rt_gram_scale": (_int, [_p, _p, _i64, _p, _int, _p]),
     "rt_gemm_tn": (_int, [_p, _p, _i64, _int, _p, _i64, _int, _i64, _i64, _i64, _p, _i64]),
@@ -40,6 +42,7 @@ SIGNATURES = {
     "rt_project_csr": (_int, [_p, _p, _p, _p, _i64, _p, _i64, _i64, _p]),
     "rt_project_csr_batched": (_int, [_p, _p, _p, _p, _i64, _int, _i64, _i64, _p, _i64, _i64, _p]),
     "rt_dense_solve_batched": (_int, [_p, _p, _p, _i64, _i64, _p]),
+    "rt_host_jacobi_eigh": (_int, [_p, _i64, _p, _p, _int, C.POINTER(_int)]),
     "rt_bench_mfma_f64": (_int, [_p, _int, C.POINTER(C.c_double)]),
     "rt_bench_copy": (_int, [_p, _p, _p, _i64, _int, C.POINTER(C.c_double)]),
 }
@@ -117,6 +120,15 @@ class Context:
             msg = self.lib.rt_last_error(self.handle)
             raise RomtimeHipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
         return rc
+
+    def set_profile(self, on: bool):
+        self.profiling = bool(on)
+        self.lib.rt_ctx_set_profile(self.handle, int(bool(on)))
+
+    def last_gemm_ms(self) -> float:
+        out = C.c_double()
+        self.check(self.lib.rt_last_gemm_ms(self.handle, C.byref(out)), "rt_last_gemm_ms")
+        return out.value
 
     def launch_info(self):
         buf = (_i64 * 3)()

@@ -110,6 +110,8 @@ void rt_ctx_destroy(rt_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->scratch2) (void)hipFree(ctx->scratch2);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   delete ctx;
 }
 
@@ -132,6 +134,26 @@ int rt_last_launch_info(rt_ctx* ctx, int64_t* info3) {
   info3[0] = ctx->last_grid;
   info3[1] = ctx->last_splits;
   info3[2] = ctx->last_tile;
+  return RT_OK;
+}
+
+int rt_ctx_set_profile(rt_ctx* ctx, int on) {
+  if (!ctx) return RT_ERR_ARG;
+  ctx->profile = (on != 0);
+  ctx->ev_valid = false;
+  return RT_OK;
+}
+
+int rt_last_gemm_ms(rt_ctx* ctx, double* ms) {
+  if (!ctx || !ms) return RT_ERR_ARG;
+  if (!ctx->ev_valid) {
+    ctx->err = "rt_last_gemm_ms: no profiled GEMM launch recorded";
+    return RT_ERR_ARG;
+  }
+  RT_HIP_CHECK(ctx, hipEventSynchronize(ctx->ev1));
+  float f = 0.f;
+  RT_HIP_CHECK(ctx, hipEventElapsedTime(&f, ctx->ev0, ctx->ev1));
+  *ms = f;
   return RT_OK;
 }
 

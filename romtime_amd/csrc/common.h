@@ -16,6 +16,9 @@ struct rt_ctx {
   int num_cus = 256;
   std::string err;
   int64_t last_grid = 0, last_splits = 0, last_tile = 0;
+  bool profile = false;             // bracket the main GEMM kernel with events (rt_ctx_set_profile)
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool ev_valid = false;
 };
 
 #define RT_HIP_CHECK(ctx, expr)                                                              \

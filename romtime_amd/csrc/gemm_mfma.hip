@@ -334,6 +334,13 @@ int rt_gemm_strided(rt_ctx* ctx, const double* A, int64_t a_ks, int64_t a_ms, co
   ctx->last_grid = grid; ctx->last_splits = splits; ctx->last_tile = BM * 1000 + BN;
 
   int rc;
+  if (ctx->profile) {
+    if (!ctx->ev0) {
+      RT_HIP_CHECK(ctx, hipEventCreate(&ctx->ev0));
+      RT_HIP_CHECK(ctx, hipEventCreate(&ctx->ev1));
+    }
+    RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  }
   switch (mt) {
     case 1: rc = launch_nt<1>(ctx, p, grid, nt, kca, kcb); break;
     case 2: rc = launch_nt<2>(ctx, p, grid, nt, kca, kcb); break;
@@ -341,6 +348,10 @@ int rt_gemm_strided(rt_ctx* ctx, const double* A, int64_t a_ks, int64_t a_ms, co
     default: rc = launch_nt<4>(ctx, p, grid, nt, kca, kcb); break;
   }
   if (rc != RT_OK) return rc;
+  if (ctx->profile) {
+    RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->ev_valid = true;
+  }
   if (use_slab) {
     const long total = M * Nn;
     hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,

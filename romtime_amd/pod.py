@@ -1,0 +1,175 @@
+"""POD basis by the method of snapshots on the MI355X (stands where rom/pod.py:7-62 stands).
+
+``orth`` keeps the reference's signature, return values (ALL singular values and the energy
+curve, not only the kept ones) and truncation precedence ``tol`` > ``num`` > ``DROP_TOLERANCE``.
+
+Algorithm (device work through the C ABI, see include/romtime_hip.h):
+
+  pass 1   G = X^T X                        rt_gram        (FP64 MFMA; the only O(N n^2) step)
+           [row-sharded X: all-reduce G over RCCL/xGMI here]
+           colnorm = sqrt(diag G), G <- D^-1 G D^-1        rt_gram_scale  (normalize=True, pod.py:31-33)
+           G = W L W^T                      small n x n symmetric eigenproblem (host LAPACK)
+           sigma = sqrt(L), energy, truncation -> r
+           Q = X (D^-1 W_r S_r^-1)          rt_gemm_nn     (back-projection)
+
+  pass 2   (only when a kept mode has sigma_r/sigma_1 < TWO_PASS_RATIO, or passes=2)
+           Y = X (D^-1 W)   full rotation   rt_gemm_nn
+           G2 = Y^T Y                       rt_gram  [+ all-reduce]
+           G2 = W2 L2 W2^T                  rt_host_jacobi_eigh (relative accuracy on the graded G2)
+           Q = Y (W2_r S_r^-1)              rt_gemm_nn
+
+One pass reproduces dgesvd's left singular vectors to ~eps (sigma_1/sigma_i)^2; the second
+pass brings that to ~eps sigma_1/sigma_i, which is dgesvd's own accuracy (measured against a
+long-double Jacobi SVD; DESIGN.md "POD accuracy").
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+
+DROP_TOLERANCE = 1e-7  # pod.py:4 (the reference's docstring says 1e-8; the code is 1e-7)
+TWO_PASS_RATIO = 1e-2  # one Gram pass: vectors good to ~eps (sigma_1/sigma_i)^2 <= 2e-12 above this ratio
+
+
+# stage timings of the most recent pod_device call (host wall clock, ms); filled only when the
+# ctx is in profile mode (rt_ctx_set_profile), which bench.py switches on for its timed region
+LAST_TIMINGS: dict = {}
+
+
+def truncation_rank(s, energy, num=None, tol=None) -> int:
+    """Number of modes kept, with the reference's precedence (pod.py:46-57).
+
+    ``energy < tol`` is strict, so the mode that crosses ``tol`` is excluded; the energy curve is
+    non-decreasing and ``s`` non-increasing, hence every mask is a prefix."""
+    if tol:
+        return int(np.count_nonzero(energy < tol))
+    if num:
+        return int(min(num, len(s)))
+    return int(np.count_nonzero(s > DROP_TOLERANCE))
+
+
+def _profiling(ctx) -> bool:
+    return bool(getattr(ctx, "profiling", False))
+
+
+def _eigh_desc(G: np.ndarray):
+    lam, W = np.linalg.eigh(G)
+    return lam[::-1].copy(), np.ascontiguousarray(W[:, ::-1])
+
+
+def jacobi_eigh(G: np.ndarray, max_sweeps: int = 40):
+    """Host two-sided Jacobi (rt_host_jacobi_eigh): eigenvalues descending, eigenvectors in columns."""
+    lib = _lib.load()
+    n = G.shape[0]
+    A = np.array(G, dtype=np.float64, order="C", copy=True)
+    W = np.empty((n, n))
+    lam = np.empty(n)
+    sweeps = C.c_int(0)
+    rc = lib.rt_host_jacobi_eigh(A.ctypes.data, n, W.ctypes.data, lam.ctypes.data, max_sweeps, C.byref(sweeps))
+    if rc != 0:
+        raise _lib.RomtimeHipError(f"rt_host_jacobi_eigh failed ({rc})")
+    return lam, W
+
+
+def _energy(s):
+    ev = np.power(s, 2)
+    return np.cumsum(ev) / np.sum(ev)
+
+
+def _inv_or_zero(s):
+    out = np.zeros_like(s)
+    nz = s > 0
+    out[nz] = 1.0 / s[nz]
+    return out
+
+
+def pod_device(X: torch.Tensor, num=None, tol=None, normalize=True, passes=None, group=None, want_vt=False):
+    """POD of a device-resident snapshot matrix (N_local x n).  Returns a dict with
+    ``Q`` (device, N_local x r, row-major), ``s``, ``energy`` (host, all n), ``VT`` (host r x n
+    or None), ``r``, ``passes``.  With ``group`` (a torch.distributed process group) X is this
+    rank's row slab and the Gram matrices are summed over the group."""
+    if X.dim() != 2:
+        raise ValueError("snapshots must be a 2-D array")
+    n = X.shape[1]
+
+    def allreduce(G):
+        if group is not None:
+            import torch.distributed as dist
+
+            dist.all_reduce(G, op=dist.ReduceOp.SUM, group=group)
+        return G
+
+    import time
+
+    ctx = _lib.Context.current() if X.is_cuda else None
+    prof = bool(ctx is not None and ctx.lib is not None and _profiling(ctx))
+    t0 = time.perf_counter()
+    G = ops.gram(X)
+    if prof:
+        LAST_TIMINGS.clear()
+        LAST_TIMINGS["gram_kernel_ms"] = ctx.last_gemm_ms()
+        LAST_TIMINGS["gram_ms"] = 1e3 * (time.perf_counter() - t0)
+    G = allreduce(G)
+    colnorm, flag = ops.gram_scale(G, normalize)
+    Gh = G.cpu().numpy()
+    t1 = time.perf_counter()
+    if normalize and int(flag.item()) != 0:
+        # the reference divides by a zero norm and scipy.linalg.svd then rejects the NaNs (pod.py:32-38)
+        raise ValueError("array must not contain infs or NaNs (zero-norm snapshot with normalize=True)")
+    lam, W = _eigh_desc(Gh)
+    t2 = time.perf_counter()
+    s = np.sqrt(np.clip(lam, 0.0, None))
+    energy = _energy(s)
+    r = truncation_rank(s, energy, num=num, tol=tol)
+    dinv = (1.0 / colnorm.cpu().numpy()) if normalize else None
+
+    if passes is None:
+        passes = 2 if (r > 0 and s[0] > 0 and s[r - 1] < TWO_PASS_RATIO * s[0]) else 1
+
+    if passes == 1:
+        T = W[:, :r] * _inv_or_zero(s[:r])
+        if dinv is not None:
+            T = T * dinv[:, None]
+        Q = ops.gemm_nn(X, ops.to_device(T, X.device)) if r > 0 else X.new_zeros((X.shape[0], 0))
+        VT = np.ascontiguousarray(W[:, :r].T) if want_vt else None
+    else:
+        T1 = W if dinv is None else W * dinv[:, None]
+        Y = ops.gemm_nn(X, ops.to_device(T1, X.device))
+        G2 = allreduce(ops.gram(Y)).cpu().numpy()
+        lam2, W2 = jacobi_eigh(G2)
+        s = np.sqrt(np.clip(lam2, 0.0, None))
+        energy = _energy(s)
+        r = truncation_rank(s, energy, num=num, tol=tol)
+        T2 = W2[:, :r] * _inv_or_zero(s[:r])
+        Q = ops.gemm_nn(Y, ops.to_device(T2, X.device)) if r > 0 else X.new_zeros((X.shape[0], 0))
+        VT = np.ascontiguousarray((W @ W2[:, :r]).T) if want_vt else None
+    if prof:
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        LAST_TIMINGS["allreduce_scale_d2h_ms"] = 1e3 * (t1 - t0) - LAST_TIMINGS["gram_ms"]
+        LAST_TIMINGS["eig_host_ms"] = 1e3 * (t2 - t1)
+        LAST_TIMINGS["backproject_ms"] = 1e3 * (t3 - t2)
+        LAST_TIMINGS["total_ms"] = 1e3 * (t3 - t0)
+    return dict(Q=Q, s=s, energy=energy, VT=VT, r=r, passes=passes, colnorm=colnorm)
+
+
+def orth(snapshots, num=None, tol=None, normalize=True, return_VT=False, passes=None, group=None):
+    """Drop-in for ``romtime.rom.pod.orth`` (pod.py:7-62).
+
+    ndarray in -> ndarrays out ``(Q, s, energy[, VT])``; a float64 CUDA tensor in -> ``Q`` stays on
+    the device (``s``, ``energy``, ``VT`` are small host arrays).  Columns of ``Q`` are defined up
+    to sign, as with any SVD.  ``passes`` (None = automatic, 1, 2) and ``group`` are extensions."""
+    if isinstance(snapshots, list):
+        raise ValueError("You should use an array, not a list.")
+    on_host = not isinstance(snapshots, torch.Tensor)
+    X = ops.to_device(snapshots)
+    out = pod_device(X, num=num, tol=tol, normalize=(normalize == True), passes=passes, group=group,  # noqa: E712
+                     want_vt=return_VT)
+    Q = out["Q"].cpu().numpy() if on_host else out["Q"]
+    if return_VT:
+        return Q, out["s"], out["energy"], out["VT"]
+    return Q, out["s"], out["energy"]

@@ -163,6 +163,41 @@ class MockBurgers(MockSolver):
     def assemble_nonlinear_lifting(self, mu, t, entries=None):
         return self._assemble_matrix(self._trilinear_elem(self.lifting(mu, t)), entries)
 
+    def solve(self):
+        """Full-order BDF time loop (host, SciPy sparse LU) producing ``solutions`` and
+        ``nonlinear_snapshots`` the way ``OneDimensionalSolver.solve`` does (fom/base.py:693-831):
+        snapshots hold the homogeneous part, ``fom`` adds the lifting."""
+        from scipy.sparse.linalg import spsolve
+
+        from ..storage import SolutionsStorage
+
+        mu, dt = self.mu, self.dt
+        u_n = np.zeros(self.Nh)
+        u_n1 = None
+        t = 0.0
+        ts, homog, full, xs = [], [], [], []
+        self.nonlinear_snapshots = [np.zeros(1)]
+        for step in range(self.nt):
+            t += dt
+            bdf = 1.5 if (self.bdf2 and step > 0) else 1.0
+            u_star = u_n if (u_n1 is None or not self.bdf2) else 2.0 * u_n - u_n1
+            M = self.assemble_mass(mu, t)
+            Nmat = self.assemble_trilinear(mu, t, u_star)
+            K = bdf * M + dt * (self.assemble_stiffness(mu, t) + self.assemble_convection(mu, t) + Nmat
+                                + self.assemble_nonlinear_lifting(mu, t))
+            past = u_n if (u_n1 is None or not self.bdf2 or step == 0) else 2.0 * u_n - 0.5 * u_n1
+            rhs = M.dot(past) + dt * self.assemble_lifting(mu, t)
+            rhs[0] = rhs[-1] = 0.0
+            u = spsolve(K.tocsc(), rhs)
+            self.nonlinear_snapshots.append(Nmat.data.copy())
+            u_n1, u_n = u_n, u
+            ts.append(t)
+            homog.append(u.copy())
+            full.append(u + self.lifting(mu, t))
+            xs.append(self.x_at(mu, t).reshape(-1, 1))
+        self.solutions = SolutionsStorage(ts=ts, mu=mu, domain=np.hstack(xs), fom=np.array(full).T,
+                                          snapshots=np.array(homog).T)
+
     def assemble_lifting(self, mu, t, entries=None):
         x = self.x_at(mu, t)
         h = self._h(mu, t)

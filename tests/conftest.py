@@ -36,3 +36,12 @@ def golden_rom():
 @pytest.fixture(scope="session")
 def golden_sampler():
     return load_golden("sampler.npz")
+
+
+@pytest.fixture
+def cpu_ops(monkeypatch):
+    """Host-logic tests: swap the device operators for the oracle's arithmetic (tests/cpu_stub.py)."""
+    from tests import cpu_stub
+
+    cpu_stub.install(monkeypatch)
+    return cpu_stub
