@@ -57,7 +57,16 @@ def _profiling(ctx) -> bool:
 
 
 def _eigh_desc(G: np.ndarray):
-    lam, W = np.linalg.eigh(G)
+    """Small symmetric eigenproblem of the n x n Gram matrix on the host (LAPACK dsyevd), eigenvalues
+    descending.  BLAS threads are capped: the problem is tiny and a GPU box gives one process a
+    16-core share of a much larger socket."""
+    try:
+        from threadpoolctl import threadpool_limits
+
+        with threadpool_limits(limits=8):
+            lam, W = np.linalg.eigh(G)
+    except ImportError:
+        lam, W = np.linalg.eigh(G)
     return lam[::-1].copy(), np.ascontiguousarray(W[:, ::-1])
 
 
