@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libromtime_hip.so")
-SOURCES = ["api.hip", "gemm_mfma.hip", "deim.hip", "sparse.hip", "solve.hip", "jacobi_host.hip"]
+SOURCES = ["api.hip", "gemm_mfma.hip", "gram_mfma.hip", "deim.hip", "sparse.hip", "solve.hip", "jacobi_host.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
@@ -35,7 +35,7 @@ def _stale(target, deps):
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "romtime_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_panel.h"), os.path.join(HERE, "..", "include", "romtime_hip.h")]
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

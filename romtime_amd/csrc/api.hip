@@ -60,17 +60,21 @@ __global__ void transpose_kernel(const double* __restrict__ src, long rows, long
   }
 }
 
+// NACC independent accumulator chains per wave; operands vary per lane so the data is not trivial
+template <int NACC>
 __global__ __launch_bounds__(256) void mfma_f64_peak_kernel(int iters, double* sink) {
-  d4 a0{0, 0, 0, 0}, a1 = a0, a2 = a0, a3 = a0;
-  const double x = 1.0 + threadIdx.x * 1e-9, y = 1.0 - threadIdx.x * 1e-9;
-  for (int i = 0; i < iters; ++i) {
-    a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, y, a0, 0, 0, 0);
-    a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, x, a1, 0, 0, 0);
-    a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(x, x, a2, 0, 0, 0);
-    a3 = __builtin_amdgcn_mfma_f64_16x16x4f64(y, y, a3, 0, 0, 0);
+  d4 acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = d4{0, 0, 0, 0};
+  double x = 1.0 + threadIdx.x * 1.1e-3, y = 0.7 - threadIdx.x * 0.9e-3;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f64_16x16x4f64((i & 1) ? x : y, (i & 2) ? x : y, acc[i], 0, 0, 0);
   }
-  const d4 s = a0 + a1 + a2 + a3;
-  if (s[0] + s[1] + s[2] + s[3] == -1.0) sink[0] = s[0];
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) s += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  if (s == -1.2345) sink[0] = s;
 }
 
 __global__ __launch_bounds__(256) void copy_kernel(double4* __restrict__ dst, const double4* __restrict__ src, long n4) {
@@ -163,6 +167,8 @@ int rt_gram(rt_ctx* ctx, const double* X, int64_t n_rows, int64_t n_cols, int64_
   RT_ARG_CHECK(ctx, layout == RT_ROW_MAJOR || layout == RT_COL_MAJOR);
   RT_ARG_CHECK(ctx, ld >= (layout == RT_ROW_MAJOR ? n_cols : n_rows));
   const int64_t ks = (layout == RT_ROW_MAJOR) ? ld : 1, ms = (layout == RT_ROW_MAJOR) ? 1 : ld;
+  const int rc = rt_gram128(ctx, X, ks, ms, n_rows, n_cols, G);
+  if (rc != RT_ERR_UNSUPPORTED) return rc;
   return rt_gemm_strided(ctx, X, ks, ms, X, ks, ms, n_rows, n_cols, n_cols, G, n_cols, 1, true, true);
 }
 
@@ -218,23 +224,36 @@ int rt_transpose(rt_ctx* ctx, const double* src, int64_t rows, int64_t cols, int
 }
 
 int rt_bench_mfma_f64(rt_ctx* ctx, int iters, double* tflops) {
+  // iters encodes the variant: low 24 bits = iterations, bits 24..27 = log2(accumulators) (0 -> 4),
+  // bits 28..30 = workgroups per CU (0 -> 2)
   if (!ctx || !tflops || iters < 1) return RT_ERR_ARG;
+  const int n_it = iters & 0xffffff;
+  const int lacc = (iters >> 24) & 15, wgcu = ((iters >> 28) & 7) ? ((iters >> 28) & 7) : 2;
+  const int nacc = lacc ? (1 << lacc) : 4;
   void* sink = nullptr;
   int rc = rt_scratch(ctx, 256, &sink);
   if (rc != RT_OK) return rc;
-  const int grid = ctx->num_cus * 2;  // 2 x 4 waves per CU = 2 waves per SIMD
+  const int grid = ctx->num_cus * wgcu;
   hipEvent_t e0, e1;
   RT_HIP_CHECK(ctx, hipEventCreate(&e0));
   RT_HIP_CHECK(ctx, hipEventCreate(&e1));
-  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(grid), dim3(256), 0, ctx->stream, iters / 10 + 1,
-                     static_cast<double*>(sink));
+  auto launch = [&](int its) {
+    double* sk = static_cast<double*>(sink);
+    switch (nacc) {
+      case 2: hipLaunchKernelGGL(mfma_f64_peak_kernel<2>, dim3(grid), dim3(256), 0, ctx->stream, its, sk); break;
+      case 8: hipLaunchKernelGGL(mfma_f64_peak_kernel<8>, dim3(grid), dim3(256), 0, ctx->stream, its, sk); break;
+      case 16: hipLaunchKernelGGL(mfma_f64_peak_kernel<16>, dim3(grid), dim3(256), 0, ctx->stream, its, sk); break;
+      default: hipLaunchKernelGGL(mfma_f64_peak_kernel<4>, dim3(grid), dim3(256), 0, ctx->stream, its, sk); break;
+    }
+  };
+  launch(n_it);  // warm-up (clock ramp)
   RT_HIP_CHECK(ctx, hipEventRecord(e0, ctx->stream));
-  hipLaunchKernelGGL(mfma_f64_peak_kernel, dim3(grid), dim3(256), 0, ctx->stream, iters, static_cast<double*>(sink));
+  launch(n_it);
   RT_HIP_CHECK(ctx, hipEventRecord(e1, ctx->stream));
   RT_HIP_CHECK(ctx, hipEventSynchronize(e1));
   float ms = 0.f;
   RT_HIP_CHECK(ctx, hipEventElapsedTime(&ms, e0, e1));
-  const double flops = (double)grid * 4 /*waves*/ * (double)iters * 4 /*mfma per iter*/ * 2048.0;
+  const double flops = (double)grid * 4 /*waves*/ * (double)n_it * nacc * 2048.0;
   *tflops = flops / (ms * 1e-3) / 1e12;
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);

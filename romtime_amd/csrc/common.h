@@ -51,3 +51,6 @@ int rt_scratch2(rt_ctx* ctx, size_t bytes, void** out);
 int rt_gemm_strided(rt_ctx* ctx, const double* A, int64_t a_ks, int64_t a_ms, const double* B, int64_t b_ks,
                     int64_t b_ns, int64_t K, int64_t M, int64_t Nn, double* C, int64_t c_rs, int64_t c_cs,
                     bool symmetric, bool allow_split);
+
+// Specialised Gram kernel (gram_mfma.hip); RT_ERR_UNSUPPORTED means "use rt_gemm_strided".
+int rt_gram128(rt_ctx* ctx, const double* X, int64_t ks, int64_t ms, int64_t K, int64_t n, double* G);

@@ -17,91 +17,11 @@
 // the slice of X they share is fetched from HBM once and re-read from that XCD's L2.
 #include "common.h"
 
-typedef double d4 __attribute__((ext_vector_type(4)));
-typedef double d2 __attribute__((ext_vector_type(2)));
+#include "gemm_panel.h"
+
+using namespace rtk;
 
 namespace {
-
-constexpr int KB = 16;            // contraction depth per LDS stage (4 MFMA k-steps)
-constexpr int NTHREADS = 256;
-constexpr int KSTRIDE = KB + 2;   // [m][k] image: 18-double rows -> conflict-free ds_read_b64
-
-struct GemmParams {
-  const double* A; long a_ks, a_ms;
-  const double* B; long b_ks, b_ns;
-  double* C; long c_rs, c_cs, c_split_stride;
-  long K, M, Nn, k_per_split;
-  int tiles_m, tiles_n, ntiles, splits, symmetric, vecA, vecB;
-};
-
-// One operand panel: KB (contraction) x BT (tile extent).
-//   KC == false: the tile axis is contiguous in memory -> LDS image [k][m], row stride BT+16
-//   KC == true : the contraction axis is contiguous   -> LDS image [m][k], row stride 18
-// Both images give each half-wave of a ds_read_b64 (lane&15 -> m, lane>>4 -> k) 32 distinct
-// 8-byte bank pairs.
-template <int BT, bool KC>
-struct Panel {
-  static constexpr int NL = (KB * BT / 2) / NTHREADS;
-  static constexpr int SM = BT + 16;
-  static constexpr int LDS = KC ? BT * KSTRIDE : KB * SM;
-
-  static __device__ __forceinline__ void load(d2 (&regs)[NL], const double* __restrict__ P, long ks, long ms,
-                                              long k0, long kend, long m0, long Mext, int vec, int tid) {
-#pragma unroll
-    for (int j = 0; j < NL; ++j) {
-      const int q = tid + NTHREADS * j;
-      int kk, i;
-      const double* p;
-      bool v0, v1;
-      if (!KC) {
-        kk = q / (BT / 2);
-        i = (q % (BT / 2)) * 2;
-        const long k = k0 + kk, m = m0 + i;
-        p = P + k * ks + m * ms;
-        v0 = (k < kend) && (m < Mext);
-        v1 = (k < kend) && (m + 1 < Mext);
-        if (vec && v1) {
-          regs[j] = *reinterpret_cast<const d2*>(p);
-        } else {
-          regs[j].x = v0 ? p[0] : 0.0;
-          regs[j].y = v1 ? p[ms] : 0.0;
-        }
-      } else {
-        i = q / (KB / 2);
-        kk = (q % (KB / 2)) * 2;
-        const long k = k0 + kk, m = m0 + i;
-        p = P + m * ms + k * ks;
-        v0 = (m < Mext) && (k < kend);
-        v1 = (m < Mext) && (k + 1 < kend);
-        if (vec && v1) {
-          regs[j] = *reinterpret_cast<const d2*>(p);
-        } else {
-          regs[j].x = v0 ? p[0] : 0.0;
-          regs[j].y = v1 ? p[ks] : 0.0;
-        }
-      }
-    }
-  }
-
-  static __device__ __forceinline__ void store(const d2 (&regs)[NL], double* s, int tid) {
-#pragma unroll
-    for (int j = 0; j < NL; ++j) {
-      const int q = tid + NTHREADS * j;
-      if (!KC) {
-        const int kk = q / (BT / 2), i = (q % (BT / 2)) * 2;
-        *reinterpret_cast<d2*>(&s[kk * SM + i]) = regs[j];
-      } else {
-        const int i = q / (KB / 2), kk = (q % (KB / 2)) * 2;
-        *reinterpret_cast<d2*>(&s[i * KSTRIDE + kk]) = regs[j];
-      }
-    }
-  }
-
-  // MFMA operand of lane (l15 = lane&15 -> tile index, l4 = lane>>4 -> k) for k-step k4
-  static __device__ __forceinline__ double frag(const double* s, int mloc, int k4, int l15, int l4) {
-    return KC ? s[(mloc + l15) * KSTRIDE + k4 * 4 + l4] : s[(k4 * 4 + l4) * SM + mloc + l15];
-  }
-};
 
 template <int MT, int NT, bool KCA, bool KCB>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_mfma_kernel(const GemmParams p) {

@@ -1,0 +1,292 @@
+// Snapshot Gram matrix G = X^T X for n >= 97 columns and long X: the dominant kernel of the POD.
+//
+// Differences from the generic strided GEMM (gemm_mfma.hip), all aimed at the two losses its
+// profile showed (profiles/r01_v1_*: 20 % of the MFMAs spent below the diagonal, L2 hit rate 26 %):
+//
+//  * XCD-local K ranges.  XCD x (workgroups with blockIdx % 8 == x) owns rows [x K/8, (x+1) K/8).
+//    Every workgroup of that XCD sweeps the SAME range, taking 16-row stages q, q+S, q+2S, ... of
+//    it, so at any moment the 64 workgroups of an XCD read a window of a few hundred consecutive
+//    rows: each 128-column panel is fetched from HBM once and re-read from that XCD's L2 by the
+//    other tiles.  A workgroup that runs ahead misses in L2 and slows down, one that lags hits and
+//    catches up, so the window stays together without any inter-workgroup protocol.
+//  * Diagonal tiles do only the 36 MFMA tiles on/above the diagonal (of 64), 9 per wave:
+//    executed/algorithmic flops 0.80 -> 0.97 at n = 512.  They run as a second launch of a
+//    DIAG instantiation (72 accumulator VGPRs instead of 128, A panel only), each launch with
+//    its own number of sub-splits so that it fills the chip evenly.
+//
+// Output: per-(XCD, slot) 128x128 slabs, summed in a fixed order by gram_reduce_kernel
+// (bitwise reproducible; exactly symmetric G).
+#include <cstdlib>
+
+#include "gemm_panel.h"
+
+using namespace rtk;
+
+namespace {
+
+constexpr int BT = 128;
+constexpr int GT = 512;         // threads per workgroup: 8 waves as 2 (M) x 4 (N), 64 x 32 per wave
+constexpr int MAX_SLOTS = 64;   // workgroups per XCD
+constexpr int MAX_TILES = 36;   // upper-triangular 128-tiles: n <= 1024
+
+struct GramParams {
+  const double* X;
+  long ks, ms;        // X(k, i) at X[k*ks + i*ms]
+  long K, n, kx;      // rows, columns, rows per XCD range (multiple of KB)
+  double* slab;       // [8][nslots][128*128]
+  int nslots, tiles1, vec, flags;  // flags: 1 = s_setprio around the MFMA block, 2 = stagger odd wave slots
+  unsigned char slot_tm[MAX_SLOTS], slot_tn[MAX_SLOTS], slot_q[MAX_SLOTS], slot_S[MAX_SLOTS];
+};
+
+// MFMA-tile sets of a diagonal 128x128 tile (8x8 grid of 16x16 tiles, only i <= j), 9 per wave.
+// Wave 0: upper triangle of the top-left quadrant minus (3,3); wave 3: that of the bottom-right
+// quadrant minus (4,4); waves 1/2: two rows each of the top-right quadrant plus (3,3) / (4,4).
+// The operands of each MFMA are read from LDS at run-time offsets (no register-array indexing),
+// so all four waves run the same instruction stream.
+__device__ const unsigned char kDiagTi[8][5] = {{0, 0, 0, 0, 1}, {1, 1, 2, 2, 3}, {0, 0, 0, 0, 1}, {1, 1, 1, 2, 2},
+                                                {2, 2, 3, 3, 3}, {3, 4, 4, 4, 4}, {5, 5, 5, 6, 255}, {6, 7, 255, 255, 255}};
+__device__ const unsigned char kDiagTj[8][5] = {{0, 1, 2, 3, 1}, {2, 3, 2, 3, 3}, {4, 5, 6, 7, 4}, {5, 6, 7, 4, 5},
+                                                {6, 7, 4, 5, 6}, {7, 4, 5, 6, 7}, {5, 6, 7, 6, 0}, {7, 7, 0, 0, 0}};
+
+template <bool KC, bool DIAG>
+__global__ __launch_bounds__(GT, 2) void gram128_kernel(const GramParams p) {
+  using P = Panel<BT, KC, GT>;
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  double* sA0 = smem;
+  double* sA1 = smem + P::LDS;
+  double* sB0 = smem + 2 * P::LDS;
+  double* sB1 = smem + 3 * P::LDS;
+
+  const int tid = threadIdx.x;
+  const int x = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int tm = p.slot_tm[slot], tn = p.slot_tn[slot], q0 = p.slot_q[slot], S = p.slot_S[slot];
+  const long m0 = (long)tm * BT, n0 = (long)tn * BT;
+  const long kbeg = (long)x * p.kx;
+  const long kend = (kbeg + p.kx < p.K) ? kbeg + p.kx : p.K;
+  const int nst_all = (kend > kbeg) ? (int)((kend - kbeg + KB - 1) / KB) : 0;
+  const int nstages = (nst_all > q0) ? (nst_all - q0 + S - 1) / S : 0;  // stages q0, q0+S, ...
+
+  const int lane = tid & 63, wid = tid >> 6;
+  const int wm = wid >> 2, wn = wid & 3;
+  const int l15 = lane & 15, l4 = lane >> 4;
+
+  constexpr int NACC = DIAG ? 5 : 8;
+  d4 acc[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) acc[i] = d4{0.0, 0.0, 0.0, 0.0};
+  int dti[5], dtj[5];  // panel-local column offsets (x16) of this wave's diagonal MFMA tiles
+  bool dval[5];
+  {
+    const int w = __builtin_amdgcn_readfirstlane(wid);
+#pragma unroll
+    for (int q = 0; q < 5; ++q) {
+      dval[q] = kDiagTi[w][q] != 255;
+      dti[q] = dval[q] ? 16 * kDiagTi[w][q] : 0;
+      dtj[q] = 16 * kDiagTj[w][q];
+    }
+  }
+
+  d2 ra[P::NL], rb[DIAG ? 1 : P::NL];
+  if (p.flags & 2) {
+    // de-phase the two waves that share a SIMD: the odd hardware wave slot starts half a stage late
+    const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((4 - 1) << 11));  // HW_REG_HW_ID[3:0] = wave_id
+    if (hw & 1) __builtin_amdgcn_s_sleep(DIAG ? 9 : 16);
+  }
+  if (nstages > 0) {
+    const long k0 = kbeg + (long)q0 * KB;
+    P::load(ra, p.X, p.ks, p.ms, k0, kend, m0, p.n, p.vec, tid);
+    if constexpr (!DIAG) P::load(rb, p.X, p.ks, p.ms, k0, kend, n0, p.n, p.vec, tid);
+    P::store(ra, sA0, tid);
+    if constexpr (!DIAG) P::store(rb, sB0, tid);
+  }
+  __syncthreads();
+
+  for (int st = 0; st < nstages; ++st) {
+    const double* cA = (st & 1) ? sA1 : sA0;
+    const double* cB = (st & 1) ? sB1 : sB0;
+    const bool more = (st + 1 < nstages) && !(p.flags & 4);  // flags & 4: timing experiment, no refills
+    if (more) {
+      const long k0 = kbeg + (long)(q0 + (st + 1) * S) * KB;
+      P::load(ra, p.X, p.ks, p.ms, k0, kend, m0, p.n, p.vec, tid);
+      if constexpr (!DIAG) P::load(rb, p.X, p.ks, p.ms, k0, kend, n0, p.n, p.vec, tid);
+    }
+    if (p.flags & 1) __builtin_amdgcn_s_setprio(1);
+    if constexpr (DIAG) {
+#pragma unroll
+      for (int k4 = 0; k4 < KB / 4; ++k4) {
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+          if (!dval[q]) continue;  // wave-uniform
+          const double a = P::frag(cA, dti[q], k4, l15, l4);
+          const double b = P::frag(cA, dtj[q], k4, l15, l4);
+          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[q], 0, 0, 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int k4 = 0; k4 < KB / 4; ++k4) {
+        double a[4], b[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a[i] = P::frag(cA, wm * 64 + i * 16, k4, l15, l4);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[j] = P::frag(cB, wn * 32 + j * 16, k4, l15, l4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i * 2 + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i * 2 + j], 0, 0, 0);
+      }
+    }
+    if (p.flags & 1) __builtin_amdgcn_s_setprio(0);
+    if (more) {
+      P::store(ra, (st & 1) ? sA0 : sA1, tid);
+      if constexpr (!DIAG) P::store(rb, (st & 1) ? sB0 : sB1, tid);
+    }
+    __syncthreads();
+  }
+
+  double* out = p.slab + ((long)x * p.nslots + slot) * (BT * BT);
+  if constexpr (DIAG) {
+#pragma unroll
+    for (int q = 0; q < 5; ++q)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (dval[q]) out[(dti[q] + l4 + 4 * r) * BT + dtj[q] + l15] = acc[q][r];
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          out[(wm * 64 + i * 16 + l4 + 4 * r) * BT + wn * 32 + j * 16 + l15] = acc[i * 2 + j][r];
+  }
+}
+
+struct GramReduceParams {
+  const double* slab_off;   // [8][nslots_off][128*128]
+  const double* slab_diag;  // [8][nslots_diag][128*128]
+  double* G;
+  long n;
+  int nslots_off, nslots_diag, tiles1;
+  unsigned char first[MAX_TILES], count[MAX_TILES];  // per upper-triangular tile, in its own launch's slots
+};
+
+__global__ void gram_reduce_kernel(const GramReduceParams p) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= p.n * p.n) return;
+  const long i = idx / p.n, j = idx % p.n;
+  const long a = (i < j) ? i : j, b = (i < j) ? j : i;  // read the upper element: exact symmetry
+  const int tm = (int)(a / BT), tn = (int)(b / BT);
+  const int t = tm * p.tiles1 - tm * (tm - 1) / 2 + (tn - tm);
+  const long off = (a % BT) * BT + (b % BT);
+  const double* slab = (tm == tn) ? p.slab_diag : p.slab_off;
+  const int nslots = (tm == tn) ? p.nslots_diag : p.nslots_off;
+  double sum = 0.0;
+  for (int x = 0; x < 8; ++x)
+    for (int q = 0; q < p.count[t]; ++q) sum += slab[((long)x * nslots + p.first[t] + q) * (BT * BT) + off];
+  p.G[idx] = sum;
+}
+
+template <bool KC, bool DIAG>
+int launch_gram(rt_ctx* ctx, const GramParams& p, int grid) {
+  constexpr size_t lds = sizeof(double) * (DIAG ? 2 : 4) * Panel<BT, KC, GT>::LDS;
+  static bool attr_set = false;
+  if (!attr_set) {
+    RT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&gram128_kernel<KC, DIAG>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gram128_kernel<KC, DIAG>), dim3(grid), dim3(GT), lds, ctx->stream, p);
+  RT_HIP_CHECK(ctx, hipGetLastError());
+  return RT_OK;
+}
+
+}  // namespace
+
+// Returns RT_ERR_UNSUPPORTED when the shape is outside this kernel's regime (caller falls back to
+// the generic symmetric GEMM).
+int rt_gram128(rt_ctx* ctx, const double* X, int64_t ks, int64_t ms, int64_t K, int64_t n, double* G) {
+  const int tiles1 = (int)((n + BT - 1) / BT);
+  const int ntiles = tiles1 * (tiles1 + 1) / 2;
+  const int n_off = ntiles - tiles1;
+  const int slots_max = 2 * ctx->num_cus / 8;  // 2 workgroups per CU, per XCD
+  if (n < 97 || ntiles > MAX_TILES || n_off > slots_max || slots_max > MAX_SLOTS || K < 8L * 64 * KB)
+    return RT_ERR_UNSUPPORTED;
+  if (!(ks == 1 || ms == 1)) return RT_ERR_UNSUPPORTED;
+  const bool kc = (ks == 1) && (ms != 1);
+
+  GramParams p;
+  p.X = X; p.ks = ks; p.ms = ms; p.K = K; p.n = n;
+  p.kx = ((K + 7) / 8 + KB - 1) / KB * KB;
+  p.tiles1 = tiles1;
+  const long other = kc ? ms : ks;
+  p.vec = ((((uintptr_t)X) & 15) == 0 && (other % 2 == 0)) ? 1 : 0;
+  static const int env_flags = [] { const char* e = getenv("ROMTIME_GRAM_FLAGS"); return e ? atoi(e) : 1; }();
+  p.flags = env_flags;
+
+  const int S_off = n_off ? slots_max / n_off : 0;   // sub-splits per off-diagonal tile per XCD
+  // too little work per workgroup: slab traffic and two launches would dominate
+  if (p.kx / KB < 48L * (S_off ? S_off : slots_max / tiles1)) return RT_ERR_UNSUPPORTED;
+  const int S_diag = slots_max / tiles1;             // ... per diagonal tile
+  const int nslots_off = S_off * n_off, nslots_diag = S_diag * tiles1;
+  const size_t tile_bytes = sizeof(double) * BT * BT;
+  void* slab = nullptr;
+  int rc = rt_scratch(ctx, tile_bytes * 8 * (size_t)(nslots_off + nslots_diag), &slab);
+  if (rc != RT_OK) return rc;
+  double* slab_off = static_cast<double*>(slab);
+  double* slab_diag = slab_off + (size_t)8 * nslots_off * BT * BT;
+
+  GramReduceParams rp;
+  rp.slab_off = slab_off; rp.slab_diag = slab_diag; rp.G = G; rp.n = n;
+  rp.nslots_off = nslots_off; rp.nslots_diag = nslots_diag; rp.tiles1 = tiles1;
+
+  if (ctx->profile) {
+    if (!ctx->ev0) {
+      RT_HIP_CHECK(ctx, hipEventCreate(&ctx->ev0));
+      RT_HIP_CHECK(ctx, hipEventCreate(&ctx->ev1));
+    }
+    RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  }
+  // launch 1: off-diagonal tiles
+  if (n_off) {
+    int slot = 0, t = 0;
+    for (int a = 0; a < tiles1; ++a)
+      for (int b = a; b < tiles1; ++b, ++t) {
+        if (a == b) continue;
+        rp.first[t] = (unsigned char)slot; rp.count[t] = (unsigned char)S_off;
+        for (int q = 0; q < S_off; ++q, ++slot) {
+          p.slot_tm[slot] = (unsigned char)a; p.slot_tn[slot] = (unsigned char)b;
+          p.slot_q[slot] = (unsigned char)q; p.slot_S[slot] = (unsigned char)S_off;
+        }
+      }
+    p.slab = slab_off; p.nslots = nslots_off;
+    rc = kc ? launch_gram<true, false>(ctx, p, 8 * nslots_off) : launch_gram<false, false>(ctx, p, 8 * nslots_off);
+    if (rc != RT_OK) return rc;
+  }
+  // launch 2: diagonal tiles (upper MFMA tiles only)
+  {
+    int slot = 0, t = 0;
+    for (int a = 0; a < tiles1; ++a)
+      for (int b = a; b < tiles1; ++b, ++t) {
+        if (a != b) continue;
+        rp.first[t] = (unsigned char)slot; rp.count[t] = (unsigned char)S_diag;
+        for (int q = 0; q < S_diag; ++q, ++slot) {
+          p.slot_tm[slot] = (unsigned char)a; p.slot_tn[slot] = (unsigned char)a;
+          p.slot_q[slot] = (unsigned char)q; p.slot_S[slot] = (unsigned char)S_diag;
+        }
+      }
+    p.slab = slab_diag; p.nslots = nslots_diag;
+    rc = kc ? launch_gram<true, true>(ctx, p, 8 * nslots_diag) : launch_gram<false, true>(ctx, p, 8 * nslots_diag);
+    if (rc != RT_OK) return rc;
+  }
+  if (ctx->profile) {
+    RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->ev_valid = true;
+  }
+  ctx->last_grid = 8 * (nslots_off + nslots_diag); ctx->last_splits = 8 * S_off; ctx->last_tile = 128 * 1000 + 128;
+  const long total = n * n;
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, rp);
+  RT_HIP_CHECK(ctx, hipGetLastError());
+  return RT_OK;
+}

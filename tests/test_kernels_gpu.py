@@ -20,7 +20,8 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-300)
 
 
-@pytest.mark.parametrize("N,n", [(1, 1), (7, 3), (64, 16), (1000, 64), (777, 33), (4099, 130), (20000, 256), (3000, 512)])
+@pytest.mark.parametrize("N,n", [(1, 1), (7, 3), (64, 16), (1000, 64), (777, 33), (4099, 130), (20000, 256), (3000, 512),
+                                 (70001, 200), (33000, 384), (50003, 512), (9000, 97), (16400, 640)])
 @pytest.mark.parametrize("order", ["C", "F"])
 def test_gram(ops, N, n, order):
     rng = np.random.RandomState(N + n)
