@@ -121,6 +121,17 @@ int rt_project_csr_batched(rt_ctx* ctx, const int64_t* indptr, const int64_t* in
  * info (B device ints, may be NULL): 0, or RT_WARN_SINGULAR. r <= 128. */
 int rt_dense_solve_batched(rt_ctx* ctx, double* K, double* rhs, int64_t r, int64_t B, int* info);
 
+/* ---- small symmetric eigenproblem of the Gram matrix, on the device (3 <= n <= 512) ----------- */
+/* Householder tridiagonalisation (16 workgroups, matrix resident in LDS) + Sturm multisection:
+ * lam (n, device) = all eigenvalues of the symmetric G (n x n row-major, not modified), DESCENDING.
+ * status (device int, may be NULL): 0, or 1 if the inter-workgroup hand-off timed out (results
+ * invalid).  Replaces the eigenvalue half of LAPACK's work inside scipy.linalg.svd (pod.py:38). */
+int rt_sym_eig_values(rt_ctx* ctx, const double* G, int64_t n, double* lam, int* status);
+/* Eigenvectors of the k LARGEST eigenvalues by inverse iteration on the tridiagonal form and
+ * back-transformation; must directly follow rt_sym_eig_values on the same ctx (it reuses the
+ * reflectors kept in the ctx's workspace).  W: n x k row-major, column t pairs with lam[t]. */
+int rt_sym_eig_vectors(rt_ctx* ctx, int64_t n, int64_t k, const double* lam, double* W);
+
 /* ---- host-side small dense step --------------------------------------------------------- */
 /* Cyclic two-sided Jacobi eigen-decomposition of a symmetric PSD n x n HOST matrix A (row-major,
  * destroyed): A = W diag(lam) W^T, lam descending, eigenvectors in the columns of W (row-major).

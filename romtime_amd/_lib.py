@@ -42,6 +42,8 @@ SIGNATURES = {
     "rt_project_csr": (_int, [_p, _p, _p, _p, _i64, _p, _i64, _i64, _p]),
     "rt_project_csr_batched": (_int, [_p, _p, _p, _p, _i64, _int, _i64, _i64, _p, _i64, _i64, _p]),
     "rt_dense_solve_batched": (_int, [_p, _p, _p, _i64, _i64, _p]),
+    "rt_sym_eig_values": (_int, [_p, _p, _i64, _p, _p]),
+    "rt_sym_eig_vectors": (_int, [_p, _i64, _i64, _p, _p]),
     "rt_host_jacobi_eigh": (_int, [_p, _i64, _p, _p, _int, C.POINTER(_int)]),
     "rt_bench_mfma_f64": (_int, [_p, _int, C.POINTER(C.c_double)]),
     "rt_bench_copy": (_int, [_p, _p, _p, _i64, _int, C.POINTER(C.c_double)]),

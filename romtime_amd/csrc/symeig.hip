@@ -1,0 +1,436 @@
+// Symmetric eigensolver for the small n x n Gram matrix of the POD (n <= 512), on the device:
+// all eigenvalues + the k leading eigenvectors, so that `orth` never leaves the GPU for the step
+// that LAPACK dsyevd (15 ms at n = 512 on the host, 13 ms in rocSOLVER) would otherwise dominate.
+//
+//   1. symeig_tridiag_kernel   Householder tridiagonalisation Q^T G Q = T (LAPACK dsytd2 recurrences).
+//      16 workgroups x 1024 threads keep G in LDS, rows dealt cyclically (row i -> workgroup i % 16,
+//      128 KiB each at n = 512), so every step's mat-vec and rank-2 update run out of LDS on 16 CUs.
+//      Two inter-workgroup hand-offs per column (the reflector, then the slices of p = tau A v) use the
+//      write-through form of the guide's inter-workgroup protocol: payload stored and loaded with
+//      agent-scope relaxed atomics (global_store/load ... sc1), every storing wave drains vmcnt,
+//      workgroup barrier, ONE lane publishes a step number / bumps a counter; ONE lane polls with
+//      s_sleep and a wall-clock bound, the others wait at a workgroup barrier.  No fences, no
+//      dependence on placement; a timeout raises an error word and every workgroup leaves.
+//   2. symeig_bisect_kernel    all eigenvalues of T by Sturm-count multisection: one wave per
+//      eigenvalue, 64 shifts per pass, 10 passes (65^10 > 2^53).
+//   3. symeig_vectors_kernel   one wave per wanted eigenvector: inverse iteration on T - lambda I
+//      (pivoted tridiagonal LU, as dstein) in LDS, then the reflectors applied in reverse.
+// The caller (pod.py) finishes with a k x k Rayleigh-Ritz step on G, which also repairs clustered
+// eigenvalues, and checks the residual; any failure falls back to... nothing silent: it raises.
+#include "common.h"
+
+namespace {
+
+constexpr int TW = 16;      // workgroups of the tridiagonalisation
+constexpr int TT = 1024;    // threads per workgroup
+constexpr int NMAX = 512;
+
+struct TriParams {
+  const double* G;   // n x n row-major (read only)
+  double* V;         // n x n: row k = Householder vector of step k (entries j > k), sc1 traffic
+  double* P;         // 2 x n: slices of p, double buffered
+  double* tau;       // n
+  double* d;         // n
+  double* e;         // n
+  int* flags;        // [0] = reflector step published, [1],[2] = slice counters, [3] = error
+  int n;
+};
+
+__device__ __forceinline__ void st_wt(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double ld_wt(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// lane 0 of the workgroup waits until *flag >= want (or the error word is set / 2 s pass)
+__device__ __forceinline__ bool wait_flag(int* flag, int want, int* err, int* s_abort) {
+  if (threadIdx.x == 0) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+    int bad = 0;
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+      __builtin_amdgcn_s_sleep(2);
+      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { bad = 1; break; }
+      if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bad = 1;
+        break;
+      }
+    }
+    *s_abort = bad;
+  }
+  __syncthreads();
+  return *s_abort == 0;
+}
+
+__device__ __forceinline__ double block_sum(double x, double* s_red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+  const int wid = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) s_red[wid] = x;
+  __syncthreads();
+  double t = 0.0;
+  for (int w = 0; w < TT / 64; ++w) t += s_red[w];  // same order in every thread
+  return t;
+}
+
+__global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int n = p.n, tid = threadIdx.x, wg = blockIdx.x;
+  const int RB = (n + TW - 1) / TW;
+  double* A = sm;                 // RB x n, local row li <-> global row li*TW + wg
+  double* sv = sm + (size_t)RB * n;
+  double* sw = sv + n;
+  double* sp = sw + n;
+  double* s_red = sp + n;         // 16 doubles
+  __shared__ int s_abort;
+  __shared__ double s_tau;
+
+  for (int q = tid; q < RB * n; q += TT) {
+    const int li = q / n, j = q % n, gi = li * TW + wg;
+    A[q] = (gi < n) ? p.G[(size_t)gi * n + j] : 0.0;
+  }
+  __syncthreads();
+
+  const int ty = tid >> 5, tx = tid & 31;  // 32 rows x 32 lanes
+  int cnt_target[2] = {0, 0};
+
+  for (int k = 0; k + 2 < n; ++k) {
+    const int owner = k % TW, lk = k / TW, m = n - k - 1;  // m = length of the reflector
+    if (wg == owner) {
+      const double* row = A + (size_t)lk * n;
+      double part = 0.0;
+      for (int j = k + 2 + tid; j < n; j += TT) part += row[j] * row[j];
+      const double xnorm2 = block_sum(part, s_red);
+      const double alpha = row[k + 1];
+      double tau, beta, scale;
+      if (xnorm2 == 0.0) {
+        tau = 0.0; beta = alpha; scale = 0.0;
+      } else {
+        beta = -copysign(sqrt(alpha * alpha + xnorm2), alpha);
+        tau = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+      }
+      double* vk = p.V + (size_t)k * n;
+      for (int j = k + 1 + tid; j < n; j += TT) st_wt(&vk[j], (j == k + 1) ? 1.0 : row[j] * scale);
+      if (tid == 0) {
+        st_wt(&p.tau[k], tau);
+        p.d[k] = row[k];
+        p.e[k] = beta;
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(&p.flags[0], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- hand-off 1: everyone takes the reflector -----------------------------------------
+    if (!wait_flag(&p.flags[0], k + 1, &p.flags[3], &s_abort)) return;
+    {
+      const double* vk = p.V + (size_t)k * n;
+      for (int j = k + 1 + tid; j < n; j += TT) sv[j] = ld_wt(&vk[j]);
+      if (tid == 0) s_tau = ld_wt(&p.tau[k]);
+    }
+    __syncthreads();
+    const double tau = s_tau;
+    if (tau == 0.0) continue;  // H = I: same decision in every workgroup
+
+    // ---- p = tau * A v on the local rows i > k ----------------------------------------------
+    double* Pk = p.P + (size_t)(k & 1) * n;
+    for (int li = ty; li < RB; li += 32) {
+      const int gi = li * TW + wg;
+      if (gi > k && gi < n) {
+        const double* row = A + (size_t)li * n;
+        double acc = 0.0;
+        for (int j = k + 1 + tx; j < n; j += 32) acc = fma(row[j], sv[j], acc);
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+        if (tx == 0) st_wt(&Pk[gi], tau * acc);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(&p.flags[1 + (k & 1)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    cnt_target[k & 1] += TW;
+    // ---- hand-off 2: everyone takes the whole p ----------------------------------------------
+    if (!wait_flag(&p.flags[1 + (k & 1)], cnt_target[k & 1], &p.flags[3], &s_abort)) return;
+    for (int j = k + 1 + tid; j < n; j += TT) sp[j] = ld_wt(&Pk[j]);
+    __syncthreads();
+    double part = 0.0;
+    for (int j = k + 1 + tid; j < n; j += TT) part += sp[j] * sv[j];
+    const double alpha2 = -0.5 * tau * block_sum(part, s_red);
+    for (int j = k + 1 + tid; j < n; j += TT) sw[j] = fma(alpha2, sv[j], sp[j]);
+    __syncthreads();
+    // ---- A <- A - v w^T - w v^T on the local rows i > k ---------------------------------------
+    for (int li = ty; li < RB; li += 32) {
+      const int gi = li * TW + wg;
+      if (gi > k && gi < n) {
+        double* row = A + (size_t)li * n;
+        const double vi = sv[gi], wi = sw[gi];
+        for (int j = k + 1 + tx; j < n; j += 32) row[j] -= vi * sw[j] + wi * sv[j];
+      }
+    }
+    __syncthreads();
+    (void)m;
+  }
+  // trailing 2 x 2
+  if (n >= 2) {
+    const int k = n - 2;
+    if (wg == k % TW && tid == 0) {
+      const double* row = A + (size_t)(k / TW) * n;
+      p.d[k] = row[k];
+      p.e[k] = row[k + 1];
+    }
+  }
+  if (wg == (n - 1) % TW && tid == 0) {
+    p.d[n - 1] = A[(size_t)((n - 1) / TW) * n + (n - 1)];
+    p.e[n - 1] = 0.0;
+  }
+}
+
+// number of eigenvalues of T smaller than x (Sturm count, dstebz recurrence)
+__device__ __forceinline__ int sturm_count(const double* d, const double* e2, int n, double x, double pivmin) {
+  double q = d[0] - x;
+  if (fabs(q) < pivmin) q = -pivmin;
+  int c = (q < 0.0);
+  for (int i = 1; i < n; ++i) {
+    q = d[i] - x - e2[i - 1] / q;
+    if (fabs(q) < pivmin) q = -pivmin;
+    c += (q < 0.0);
+  }
+  return c;
+}
+
+// lam[j] = j-th LARGEST eigenvalue of T; one wave per eigenvalue
+__global__ void symeig_init_kernel(int* flags, double* tau, int n) {
+  for (int i = threadIdx.x; i < 8; i += blockDim.x) flags[i] = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) tau[i] = 0.0;
+}
+
+__global__ __launch_bounds__(TT) void symeig_bisect_kernel(const double* __restrict__ d, const double* __restrict__ e,
+                                                           int n, double* __restrict__ lam, const int* flags,
+                                                           int* status) {
+  if (status && blockIdx.x == 0 && threadIdx.x == 0) *status = flags[3];
+  __shared__ double sd[NMAX], se2[NMAX];
+  __shared__ double s_red[4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < n; i += TT) {
+    sd[i] = d[i];
+    se2[i] = (i + 1 < n) ? e[i] * e[i] : 0.0;
+  }
+  __syncthreads();
+  // Gershgorin interval and pivmin, redundantly per wave (wave 0 publishes)
+  if (tid < 64) {
+    double lo = 1e300, hi = -1e300, emax = 0.0;
+    for (int i = lane; i < n; i += 64) {
+      const double el = (i > 0) ? fabs(e[i - 1]) : 0.0, er = (i + 1 < n) ? fabs(e[i]) : 0.0;
+      lo = fmin(lo, sd[i] - el - er);
+      hi = fmax(hi, sd[i] + el + er);
+      emax = fmax(emax, se2[i]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      lo = fmin(lo, __shfl_xor(lo, off));
+      hi = fmax(hi, __shfl_xor(hi, off));
+      emax = fmax(emax, __shfl_xor(emax, off));
+    }
+    if (lane == 0) {
+      const double tn = fmax(fabs(lo), fabs(hi));
+      s_red[0] = lo - 2.2e-16 * tn * n - 1e-300;
+      s_red[1] = hi + 2.2e-16 * tn * n + 1e-300;
+      s_red[2] = 2.2250738585072014e-308 * fmax(1.0, emax);
+    }
+  }
+  __syncthreads();
+  const int j = blockIdx.x * (TT / 64) + (tid >> 6);  // descending index
+  if (j >= n) return;
+  const int want = n - j;  // ascending rank (1-based): smallest x with count(x) >= want
+  double lo = s_red[0], hi = s_red[1];
+  const double pivmin = s_red[2];
+  for (int pass = 0; pass < 10; ++pass) {
+    const double h = (hi - lo) / 65.0;
+    const double x = lo + h * (lane + 1);
+    const int c = sturm_count(sd, se2, n, x, pivmin);
+    const unsigned long long ge = __ballot(c >= want);
+    if (ge == 0ull) {
+      lo = lo + h * 64;
+    } else {
+      const int first = __ffsll((long long)ge) - 1;
+      hi = lo + h * (first + 1);
+      lo = lo + h * first;
+    }
+  }
+  if (lane == 0) lam[j] = 0.5 * (lo + hi);
+}
+
+struct VecParams {
+  const double* d;
+  const double* e;
+  const double* lam;   // descending
+  const double* V;     // reflectors
+  const double* tau;
+  double* W;           // n x k row-major output: column t = eigenvector of lam[t]
+  int n, k;
+};
+
+// one wave per eigenvector: inverse iteration on T - lambda I, then back-transformation
+__global__ __launch_bounds__(64) void symeig_vectors_kernel(const VecParams p) {
+  __shared__ double a[NMAX], b[NMAX], c[NMAX], d2[NMAX], z[NMAX];
+  __shared__ unsigned char piv[NMAX];
+  const int n = p.n, t = blockIdx.x, lane = threadIdx.x;
+  const double lambda = p.lam[t];
+  double tnorm = 0.0;
+  for (int i = lane; i < n; i += 64) {
+    a[i] = p.d[i] - lambda;
+    b[i] = (i + 1 < n) ? p.e[i] : 0.0;   // superdiagonal
+    c[i] = (i + 1 < n) ? p.e[i] : 0.0;   // subdiagonal (row i+1)
+    d2[i] = 0.0;
+    tnorm = fmax(tnorm, fabs(p.d[i]) + 2.0 * ((i + 1 < n) ? fabs(p.e[i]) : 0.0));
+    // deterministic start vector in (-1, 1), different for every eigenvector
+    unsigned s = 1664525u * (unsigned)(i + 1 + 7919 * (t + 1)) + 1013904223u;
+    s ^= s >> 15; s *= 2246822519u; s ^= s >> 13;
+    z[i] = (double)(s & 0xffffff) / 8388608.0 - 1.0;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) tnorm = fmax(tnorm, __shfl_xor(tnorm, off));
+  const double tiny = 2.2e-16 * fmax(tnorm, 1e-300);
+  __syncthreads();
+  if (lane == 0) {
+    // P L U = T - lambda I with partial pivoting (dlagtf recurrences)
+    for (int k = 0; k + 1 < n; ++k) {
+      if (fabs(c[k]) <= fabs(a[k])) {
+        piv[k] = 0;
+        const double ak = (a[k] == 0.0) ? tiny : a[k];
+        const double mult = c[k] / ak;
+        a[k + 1] -= mult * b[k];
+        c[k] = mult;
+      } else {
+        piv[k] = 1;
+        const double mult = a[k] / c[k];
+        a[k] = c[k];
+        const double temp = a[k + 1];
+        a[k + 1] = b[k] - mult * temp;
+        if (k + 2 < n) {
+          d2[k] = b[k + 1];
+          b[k + 1] = -mult * d2[k];
+        }
+        b[k] = temp;
+        c[k] = mult;
+      }
+    }
+    for (int it = 0; it < 4; ++it) {
+      // forward: y = L^-1 P z
+      for (int k = 0; k + 1 < n; ++k) {
+        if (piv[k]) {
+          const double tmp = z[k];
+          z[k] = z[k + 1];
+          z[k + 1] = tmp - c[k] * z[k];
+        } else {
+          z[k + 1] -= c[k] * z[k];
+        }
+      }
+      // backward: U x = y, tiny pivots perturbed (dlagts job = -1)
+      double zmax = 0.0;
+      for (int k = n - 1; k >= 0; --k) {
+        double tmp = z[k];
+        if (k + 1 < n) tmp -= b[k] * z[k + 1];
+        if (k + 2 < n) tmp -= d2[k] * z[k + 2];
+        double ak = a[k];
+        if (fabs(ak) < tiny) ak = copysign(tiny, ak == 0.0 ? 1.0 : ak);
+        z[k] = tmp / ak;
+        zmax = fmax(zmax, fabs(z[k]));
+      }
+      const double sc = 1.0 / fmax(zmax, 1e-300);
+      for (int k = 0; k < n; ++k) z[k] *= sc;
+    }
+  }
+  __syncthreads();
+  // unit 2-norm
+  double part = 0.0;
+  for (int i = lane; i < n; i += 64) part += z[i] * z[i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+  const double inv = 1.0 / sqrt(part);
+  for (int i = lane; i < n; i += 64) z[i] *= inv;
+  __syncthreads();
+  // x = Q z = H_0 H_1 ... H_{n-3} z : apply the reflectors from the last to the first
+  for (int k = n - 3; k >= 0; --k) {
+    const double tk = p.tau[k];
+    if (tk == 0.0) continue;
+    const double* vk = p.V + (size_t)k * n;
+    double dot = 0.0;
+    for (int j = k + 1 + lane; j < n; j += 64) dot = fma(vk[j], z[j], dot);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+    const double s = tk * dot;
+    for (int j = k + 1 + lane; j < n; j += 64) z[j] -= s * vk[j];
+    __syncthreads();
+  }
+  for (int i = lane; i < n; i += 64) p.W[(size_t)i * p.k + t] = z[i];
+}
+
+}  // namespace
+
+namespace {
+struct EigState {  // carved from the ctx's composite arena by rt_sym_eig_values, reused by rt_sym_eig_vectors
+  TriParams tp;
+  int64_t n = 0;
+  void* base = nullptr;
+};
+EigState g_state;  // one per process is enough: a ctx serialises its calls, and the pair is called back to back
+}  // namespace
+
+extern "C" int rt_sym_eig_values(rt_ctx* ctx, const double* G, int64_t n, double* lam, int* status) {
+  if (!ctx) return RT_ERR_ARG;
+  RT_ARG_CHECK(ctx, G && lam && n >= 3);
+  if (n > NMAX) {
+    ctx->err = "rt_sym_eig_values: n > 512 not supported (the matrix must fit the LDS of 16 CUs)";
+    return RT_ERR_UNSUPPORTED;
+  }
+  // composite arena: V (n*n) | P (2n) | tau | d | e | flags
+  size_t off = 0;
+  auto take = [&off](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  const size_t oV = take(sizeof(double) * n * n), oP = take(sizeof(double) * 2 * n), oT = take(sizeof(double) * n),
+               oD = take(sizeof(double) * n), oE = take(sizeof(double) * n), oF = take(sizeof(int) * 8);
+  void* base = nullptr;
+  int rc = rt_scratch2(ctx, off, &base);
+  if (rc != RT_OK) return rc;
+  char* b8 = static_cast<char*>(base);
+  TriParams tp;
+  tp.G = G; tp.n = (int)n;
+  tp.V = reinterpret_cast<double*>(b8 + oV); tp.P = reinterpret_cast<double*>(b8 + oP);
+  tp.tau = reinterpret_cast<double*>(b8 + oT); tp.d = reinterpret_cast<double*>(b8 + oD);
+  tp.e = reinterpret_cast<double*>(b8 + oE); tp.flags = reinterpret_cast<int*>(b8 + oF);
+  hipStream_t st = ctx->stream;
+  hipLaunchKernelGGL(symeig_init_kernel, dim3(1), dim3(256), 0, st, tp.flags, tp.tau, (int)n);
+
+  const int RB = (int)((n + TW - 1) / TW);
+  const size_t lds = sizeof(double) * ((size_t)RB * n + 3 * n + 16);
+  static bool attr_set = false;
+  if (!attr_set) {
+    RT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&symeig_tridiag_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(symeig_tridiag_kernel, dim3(TW), dim3(TT), lds, st, tp);
+  RT_HIP_CHECK(ctx, hipGetLastError());
+  hipLaunchKernelGGL(symeig_bisect_kernel, dim3((unsigned)((n + 15) / 16)), dim3(TT), 0, st, tp.d, tp.e, (int)n, lam,
+                     tp.flags, status);
+  RT_HIP_CHECK(ctx, hipGetLastError());
+  g_state.tp = tp; g_state.n = n; g_state.base = base;
+  return RT_OK;
+}
+
+extern "C" int rt_sym_eig_vectors(rt_ctx* ctx, int64_t n, int64_t k, const double* lam, double* W) {
+  if (!ctx) return RT_ERR_ARG;
+  RT_ARG_CHECK(ctx, lam && W && k >= 1 && k <= n);
+  if (g_state.n != n || g_state.base == nullptr || g_state.base != ctx->scratch2) {
+    ctx->err = "rt_sym_eig_vectors: must directly follow rt_sym_eig_values on the same ctx and matrix";
+    return RT_ERR_ARG;
+  }
+  VecParams vp;
+  vp.d = g_state.tp.d; vp.e = g_state.tp.e; vp.lam = lam; vp.V = g_state.tp.V; vp.tau = g_state.tp.tau;
+  vp.W = W; vp.n = (int)n; vp.k = (int)k;
+  hipLaunchKernelGGL(symeig_vectors_kernel, dim3((unsigned)k), dim3(64), 0, ctx->stream, vp);
+  RT_HIP_CHECK(ctx, hipGetLastError());
+  return RT_OK;
+}

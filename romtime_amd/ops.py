@@ -173,6 +173,26 @@ def dense_solve(K: torch.Tensor, b: torch.Tensor):
     return (bw[0] if single else bw), info
 
 
+def sym_eig_values(G: torch.Tensor):
+    """All eigenvalues (descending, device) of the symmetric n x n G; (lam, status). rt_sym_eig_values."""
+    ctx = Context.current()
+    n = G.shape[0]
+    assert G.is_contiguous() and G.shape == (n, n)
+    lam = torch.empty(n, dtype=torch.float64, device=G.device)
+    status = torch.zeros(1, dtype=torch.int32, device=G.device)
+    ctx.check(ctx.lib.rt_sym_eig_values(ctx.handle, _ptr(G), n, _ptr(lam), _ptr(status)), "rt_sym_eig_values")
+    return lam, status
+
+
+def sym_eig_vectors(lam: torch.Tensor, k: int) -> torch.Tensor:
+    """Eigenvectors (n x k) of the k largest eigenvalues; directly after sym_eig_values. rt_sym_eig_vectors."""
+    ctx = Context.current()
+    n = lam.numel()
+    W = torch.empty((n, k), dtype=torch.float64, device=lam.device)
+    ctx.check(ctx.lib.rt_sym_eig_vectors(ctx.handle, n, k, _ptr(lam), _ptr(W)), "rt_sym_eig_vectors")
+    return W
+
+
 def transpose(src: torch.Tensor) -> torch.Tensor:
     ctx = Context.current()
     src = src.contiguous()

@@ -32,6 +32,8 @@ import torch
 from . import _lib, ops
 
 DROP_TOLERANCE = 1e-7  # pod.py:4 (the reference's docstring says 1e-8; the code is 1e-7)
+DEVICE_EIG = True      # small eigenproblem on the device (rt_sym_eig_*); False = host LAPACK
+DEVICE_EIG_MAX_N = 512
 TWO_PASS_RATIO = 1e-2  # one Gram pass: vectors good to ~eps (sigma_1/sigma_i)^2 <= 2e-12 above this ratio
 
 
@@ -56,16 +58,32 @@ def _profiling(ctx) -> bool:
     return bool(getattr(ctx, "profiling", False))
 
 
+class _blas_threads:
+    """Cap the BLAS/OpenMP pools around the small host-side dense steps.  On a GPU box one process
+    owns a 16-core share of a 256-thread socket: an uncapped OpenBLAS spins 64+ threads, exhausts
+    the cgroup's CPU quota and gets the whole process throttled for tens of milliseconds."""
+
+    def __init__(self, n):
+        self.n, self.ctx = n, None
+
+    def __enter__(self):
+        try:
+            from threadpoolctl import threadpool_limits
+
+            self.ctx = threadpool_limits(limits=self.n)
+            self.ctx.__enter__()
+        except ImportError:
+            self.ctx = None
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+
+
 def _eigh_desc(G: np.ndarray):
     """Small symmetric eigenproblem of the n x n Gram matrix on the host (LAPACK dsyevd), eigenvalues
-    descending.  BLAS threads are capped: the problem is tiny and a GPU box gives one process a
-    16-core share of a much larger socket."""
-    try:
-        from threadpoolctl import threadpool_limits
-
-        with threadpool_limits(limits=8):
-            lam, W = np.linalg.eigh(G)
-    except ImportError:
+    descending (used by the two-pass route, which needs the full rotation)."""
+    with _blas_threads(8):
         lam, W = np.linalg.eigh(G)
     return lam[::-1].copy(), np.ascontiguousarray(W[:, ::-1])
 
@@ -124,6 +142,11 @@ def pod_device(X: torch.Tensor, num=None, tol=None, normalize=True, passes=None,
         LAST_TIMINGS["gram_ms"] = 1e3 * (time.perf_counter() - t0)
     G = allreduce(G)
     colnorm, flag = ops.gram_scale(G, normalize)
+    dev_eig = X.is_cuda and passes != 2 and 3 <= n <= DEVICE_EIG_MAX_N and DEVICE_EIG
+    if dev_eig:
+        out = _pod_device_eig(X, G, colnorm, flag, normalize, num, tol, passes, want_vt, prof, t0)
+        if out is not None:
+            return out
     Gh = G.cpu().numpy()
     t1 = time.perf_counter()
     if normalize and int(flag.item()) != 0:
@@ -164,6 +187,55 @@ def pod_device(X: torch.Tensor, num=None, tol=None, normalize=True, passes=None,
         LAST_TIMINGS["backproject_ms"] = 1e3 * (t3 - t2)
         LAST_TIMINGS["total_ms"] = 1e3 * (t3 - t0)
     return dict(Q=Q, s=s, energy=energy, VT=VT, r=r, passes=passes, colnorm=colnorm)
+
+
+def _pod_device_eig(X, G, colnorm, flag, normalize, num, tol, passes, want_vt, prof, t0):
+    """Single-pass POD with the n x n eigenproblem on the device (rt_sym_eig_values/_vectors) and a
+    k x k Rayleigh-Ritz polish.  Returns None when the spectrum asks for the two-pass path (the caller
+    continues on the host-eig route, which provides the full rotation)."""
+    import time
+
+    from scipy.linalg import eigh as small_eigh
+
+    n = G.shape[0]
+    lam_d, status = ops.sym_eig_values(G)
+    head = torch.cat([lam_d, status.to(torch.float64), flag.to(torch.float64)]).cpu().numpy()  # one D2H
+    t1 = time.perf_counter()
+    lam, eig_status, zero_norm = head[:n], int(head[n]), int(head[n + 1])
+    if normalize and zero_norm != 0:
+        raise ValueError("array must not contain infs or NaNs (zero-norm snapshot with normalize=True)")
+    if eig_status != 0:
+        raise _lib.RomtimeHipError("rt_sym_eig_values: inter-workgroup hand-off timed out")
+    s = np.sqrt(np.clip(lam, 0.0, None))
+    energy = _energy(s)
+    r = truncation_rank(s, energy, num=num, tol=tol)
+    if passes is None and r > 0 and s[0] > 0 and s[r - 1] < TWO_PASS_RATIO * s[0]:
+        return None
+    if r == 0:
+        Q = X.new_zeros((X.shape[0], 0))
+        VT = np.zeros((0, n)) if want_vt else None
+    else:
+        Z = ops.sym_eig_vectors(lam_d, r)                       # n x r
+        GZ = ops.gemm_nn(G, Z)
+        HS = torch.cat([ops.gemm_tn(Z, GZ), ops.gemm_tn(Z, Z)], dim=0).cpu().numpy()
+        H, S = 0.5 * (HS[:r] + HS[:r].T), 0.5 * (HS[r:] + HS[r:].T)
+        with _blas_threads(1):                                   # k x k: threads only burn the CPU quota
+            theta, C = small_eigh(H, S)                          # generalised Rayleigh-Ritz
+        theta, C = theta[::-1], C[:, ::-1]
+        if np.abs(theta - lam[:r]).max() > 1e-9 * max(lam[0], 1e-300):
+            raise _lib.RomtimeHipError("device eigenvectors failed the Rayleigh-Ritz cross-check")
+        T2 = ops.to_device(np.ascontiguousarray(C * _inv_or_zero(s[:r])), X.device)
+        Zs = Z if not normalize else Z / colnorm[:, None]
+        Q = ops.gemm_nn(X, ops.gemm_nn(Zs.contiguous(), T2))
+        VT = np.ascontiguousarray((Z.cpu().numpy() @ C).T) if want_vt else None
+    if prof:
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        LAST_TIMINGS["allreduce_scale_eigvals_ms"] = 1e3 * (t1 - t0) - LAST_TIMINGS["gram_ms"]
+        LAST_TIMINGS["eigvec_backproject_ms"] = 1e3 * (t3 - t1)
+        LAST_TIMINGS["total_ms"] = 1e3 * (t3 - t0)
+        LAST_TIMINGS["eig_path"] = 1.0
+    return dict(Q=Q, s=s, energy=energy, VT=VT, r=r, passes=1, colnorm=colnorm)
 
 
 def orth(snapshots, num=None, tol=None, normalize=True, return_VT=False, passes=None, group=None):

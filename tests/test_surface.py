@@ -33,7 +33,14 @@ def check_orth_golden(g):
         X = g[f"X__{mname}"]
         Q, s, energy, VT = orth(X.copy(), normalize=(nname == "norm"), return_VT=True, **_branch_kwargs(bname))
         gQ, gs, ge, gVT = g[f"Q__{key}"], g[f"s__{key}"], g[f"energy__{key}"], g[f"VT__{key}"]
-        assert isinstance(Q, np.ndarray) and Q.shape == gQ.shape, (key, Q.shape, gQ.shape)
+        kw = _branch_kwargs(bname)
+        knife_edge = "tol" in kw and np.abs(ge - kw["tol"]).min() < 1e-12  # energy == tol to rounding
+        assert isinstance(Q, np.ndarray)
+        if knife_edge:  # decay_200x16, tol=0.999: energy[2] = 0.999 + 1e-16; either count is "right"
+            assert abs(Q.shape[1] - gQ.shape[1]) <= 1
+            keep = min(Q.shape[1], gQ.shape[1])
+            Q, gQ, VT, gVT = Q[:, :keep], gQ[:, :keep], VT[:keep], gVT[:keep]
+        assert Q.shape == gQ.shape, (key, Q.shape, gQ.shape)
         assert s.shape == gs.shape and energy.shape == ge.shape  # ALL singular values are returned
         # singular values: 2e-13 sigma_1 where resolved; a single Gram pass carries an absolute error
         # eps sigma_1^2 in sigma^2, i.e. ~eps sigma_1^2 / sigma_i in sigma_i (tail of the spectrum)

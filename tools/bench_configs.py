@@ -1,0 +1,147 @@
+#!/usr/bin/env python3
+"""Secondary measurements on the BASELINE.json configs that bench.py does not headline
+(C2 POD 1e5x256, C4 MDEIM greedy + project_basis, C5 online reduced steps), each next to the oracle
+on a bounded sample.  Prints one JSON object per config; results go to BASELINE.md / profiles/."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import romtime_oracle as oracle  # noqa: E402
+from romtime_amd import ops, pod  # noqa: E402
+from scipy.sparse import csr_matrix  # noqa: E402
+
+HBM, MFMA = 8000.0, 78.6
+
+
+def ev_time(fn, reps=3, warm=1):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        out = fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps, out
+
+
+def wall_time(fn, reps=3, warm=1):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        out = fn()
+    torch.cuda.synchronize()
+    return 1e3 * (time.perf_counter() - t0) / reps, out
+
+
+def penta(N, rng):
+    offs = [-2, -1, 0, 1, 2]
+    rows = np.concatenate([np.arange(max(0, -o), min(N, N - o)) for o in offs])
+    cols = np.concatenate([np.arange(max(0, -o), min(N, N - o)) + o for o in offs])
+    A = csr_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=(N, N))
+    A.sort_indices()
+    return A
+
+
+def c2():
+    N, n, r = 100_000, 256, 40
+    g = torch.Generator(device="cuda").manual_seed(2)
+    s = torch.from_numpy(10.0 ** (-6.0 * np.arange(n) / (n - 1))).cuda()
+    V0, _ = torch.linalg.qr(torch.randn((n, n), dtype=torch.float64, device="cuda", generator=g))
+    X = (torch.randn((N, n), dtype=torch.float64, device="cuda", generator=g) / np.sqrt(N)) @ (s[:, None] * V0.T)
+    ms, out = wall_time(lambda: pod.pod_device(X, num=r, normalize=True), reps=5)
+    Xh = X.cpu().numpy()
+    t0 = time.perf_counter()
+    Qr, sr, er = oracle.orth(Xh, num=r, normalize=True)
+    cpu = time.perf_counter() - t0
+    Q = out["Q"].cpu().numpy()
+    sub = np.linalg.norm(Q @ (Q.T @ Qr) - Qr, 2)
+    return dict(config="C2 POD 1e5x256 r40", gpu_ms=ms, dof_per_s=N * n / ms * 1e3, cpu_s=cpu, cpu_dof_per_s=N * n / cpu,
+                sigma_rel_err=float(np.abs(out["s"][:r] - sr[:r]).max() / sr[0]), subspace_dist=float(sub),
+                passes=out["passes"])
+
+
+def c4():
+    N, nnz_row, n_ops, m, r = 100_000, 5, 200, 120, 80
+    rng = np.random.RandomState(4)
+    A = penta(N, rng)
+    nnz = A.nnz
+    # 200 value vectors = smooth combinations of 8 spatial profiles + 1e-6 noise, row 0 zeroed
+    x = np.linspace(0, 1, nnz)
+    B = np.stack([np.sin((q + 1) * np.pi * x) * (1 + 0.1 * q) for q in range(8)], axis=1)
+    theta = rng.standard_normal((8, n_ops))
+    S = torch.from_numpy(B @ theta + 1e-6 * rng.standard_normal((nnz, n_ops))).cuda()
+    S[0, :] = 0.0
+    ms_pod, out = wall_time(lambda: pod.pod_device(S, num=m, normalize=False), reps=2)
+    Phi = out["Q"]
+    ms_greedy, g = wall_time(lambda: ops.deim_greedy(Phi, want_margin=False), reps=2)
+    greedy_bytes = 8.0 * nnz * sum(k + 2 for k in range(m))
+    V, _ = torch.linalg.qr(torch.randn((N, r), dtype=torch.float64, device="cuda"))
+    ip, ix = ops.to_device_index(A.indptr), ops.to_device_index(A.indices)
+    ms_proj, AN = wall_time(lambda: ops.project_csr_batched(ip, ix, Phi, V), reps=2)
+    proj_flops = m * (2.0 * nnz * r + 2.0 * N * r * r)
+    # oracle on a bounded sample: greedy on the first 24 modes, projection of 4 modes
+    Ph = Phi.cpu().numpy()
+    t0 = time.perf_counter()
+    dofs, _, _ = oracle.deim_greedy(Ph[:, :24])
+    cpu_greedy24 = time.perf_counter() - t0
+    Vh = V.cpu().numpy()
+    t0 = time.perf_counter()
+    ref4 = [oracle.project_csr(csr_matrix((Ph[:, i], A.indices, A.indptr), shape=(N, N)), Vh) for i in range(4)]
+    cpu_proj4 = time.perf_counter() - t0
+    idx = g[0].cpu().numpy()
+    return dict(config="C4 MDEIM 200 ops N=1e5 nnz~5e5 m=120 r=80", pod_ms=ms_pod, greedy_ms=ms_greedy,
+                greedy_GBps=greedy_bytes / ms_greedy / 1e6, greedy_hbm_frac=greedy_bytes / ms_greedy / 1e6 / HBM,
+                project_ms=ms_proj, project_TFs=proj_flops / ms_proj / 1e9, project_mfma_frac=proj_flops / ms_proj / 1e9 / MFMA,
+                cpu_greedy_first24_s=cpu_greedy24, greedy_first24_match=bool(list(idx[:24]) == list(dofs)),
+                cpu_project_4modes_s=cpu_proj4,
+                project_err=float(max(np.abs(AN[i].cpu().numpy() - ref4[i]).max() for i in range(4))))
+
+
+def c5(nt=200, n_mu=32):
+    """Online direct path per (mu, step): 2 projections (M and the pre-summed K) + r x r solve + lift."""
+    N, r = 100_000, 80
+    rng = np.random.RandomState(5)
+    A = penta(N, rng)
+    ip, ix = ops.to_device_index(A.indptr), ops.to_device_index(A.indices)
+    V, _ = torch.linalg.qr(torch.randn((N, r), dtype=torch.float64, device="cuda"))
+    Mdata = torch.from_numpy(np.abs(A.data) + 3.0).cuda()
+    Kdata = torch.randn((A.nnz, n_mu), dtype=torch.float64, device="cuda") * 0.1
+    Kdata += Mdata[:, None]
+    f = torch.randn(N, dtype=torch.float64, device="cuda")
+
+    def step():
+        MN = ops.project_csr(ip, ix, Mdata, V)
+        KN = ops.project_csr_batched(ip, ix, Kdata, V)              # (n_mu, r, r)
+        bN = ops.gemm_tn(V, f)
+        x, info = ops.dense_solve(KN, bN.unsqueeze(0).expand(n_mu, r))
+        return ops.gemm_nn(V, x.T.contiguous())                      # lift all n_mu solutions
+
+    ms, _ = wall_time(step, reps=nt // 10, warm=2)
+    flops = n_mu * 2 * (2.0 * A.nnz * r + 2.0 * N * r * r)
+    # oracle: one (mu, step)
+    Vh, Ah = V.cpu().numpy(), A
+    t0 = time.perf_counter()
+    for _ in range(3):
+        MNh = oracle.project_csr(Ah, Vh)
+        KNh = oracle.project_csr(Ah, Vh) + np.eye(r)
+        u = oracle.reduced_solve(KNh, Vh.T @ f.cpu().numpy())
+        Vh @ u
+    cpu = (time.perf_counter() - t0) / 3
+    return dict(config=f"C5 online r=80 N=1e5 {n_mu} mu per batched step (unfused kernels)", ms_per_batched_step=ms,
+                reduced_steps_per_s=n_mu / ms * 1e3, TFs=flops / ms / 1e9, mfma_frac=flops / ms / 1e9 / MFMA,
+                cpu_s_per_step=cpu, cpu_steps_per_s=1.0 / cpu)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["c2", "c4", "c5"]
+    for w in which:
+        print(json.dumps({"c2": c2, "c4": c4, "c5": c5}[w]()), flush=True)
