@@ -28,11 +28,11 @@ constexpr int NMAX = 512;
 struct TriParams {
   const double* G;   // n x n row-major (read only)
   double* V;         // n x n: row k = Householder vector of step k (entries j > k), sc1 traffic
-  double* P;         // 2 x n: slices of p, double buffered
+  double* P;         // 4 x n: slices of p (double buffered) and the look-ahead row (double buffered)
   double* tau;       // n
   double* d;         // n
   double* e;         // n
-  int* flags;        // [0] = reflector step published, [1],[2] = slice counters, [3] = error
+  int* flags;        // [1] = arrival counter of the hand-offs, [3] = error
   int n;
 };
 
@@ -75,6 +75,32 @@ __device__ __forceinline__ double block_sum(double x, double* s_red) {
   return t;
 }
 
+// Householder vector of x = row[k+1 .. n-1] (dlarfg): writes v (v[k+1] = 1) into sv, returns tau, beta.
+// Called by ALL workgroups on identical data, so every workgroup derives bit-identical (v, tau).
+__device__ __forceinline__ void make_reflector(const double* row, int k, int n, double* sv, double* s_red,
+                                               double* tau_out, double* beta_out) {
+  const int tid = threadIdx.x;
+  double part = 0.0;
+  for (int j = k + 2 + tid; j < n; j += TT) part += row[j] * row[j];
+  const double xnorm2 = block_sum(part, s_red);
+  const double alpha = row[k + 1];
+  double tau, beta, scale;
+  if (xnorm2 == 0.0) {
+    tau = 0.0; beta = alpha; scale = 0.0;
+  } else {
+    beta = -copysign(sqrt(alpha * alpha + xnorm2), alpha);
+    tau = (beta - alpha) / beta;
+    scale = 1.0 / (alpha - beta);
+  }
+  for (int j = k + 1 + tid; j < n; j += TT) sv[j] = (j == k + 1) ? 1.0 : row[j] * scale;
+  __syncthreads();
+  *tau_out = tau;
+  *beta_out = beta;
+}
+
+// One inter-workgroup hand-off per column: together with its slice of p = tau A v, the owner of row
+// k+1 publishes that row as it stands BEFORE the rank-2 update of step k; after the hand-off every
+// workgroup applies the update to its copy and derives the next reflector redundantly.
 __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int n = p.n, tid = threadIdx.x, wg = blockIdx.x;
@@ -83,84 +109,83 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
   double* sv = sm + (size_t)RB * n;
   double* sw = sv + n;
   double* sp = sw + n;
-  double* s_red = sp + n;         // 16 doubles
+  double* sl = sp + n;            // look-ahead row
+  double* s_red = sl + n;         // 16 doubles
   __shared__ int s_abort;
-  __shared__ double s_tau;
 
   for (int q = tid; q < RB * n; q += TT) {
     const int li = q / n, j = q % n, gi = li * TW + wg;
     A[q] = (gi < n) ? p.G[(size_t)gi * n + j] : 0.0;
   }
   __syncthreads();
-
   const int ty = tid >> 5, tx = tid & 31;  // 32 rows x 32 lanes
-  int cnt_target[2] = {0, 0};
+  int hop = 0;                              // counter target is hop * TW
+
+  // step "-1": row 0 to everybody
+  double* L0 = p.P + (size_t)2 * n;         // P = [p even | p odd | row even | row odd]
+  if (wg == 0)
+    for (int j = tid; j < n; j += TT) st_wt(&L0[j], A[j]);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) __hip_atomic_fetch_add(&p.flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  ++hop;
+  if (!wait_flag(&p.flags[1], hop * TW, &p.flags[3], &s_abort)) return;
+  for (int j = tid; j < n; j += TT) sl[j] = ld_wt(&L0[j]);
+  __syncthreads();
 
   for (int k = 0; k + 2 < n; ++k) {
-    const int owner = k % TW, lk = k / TW, m = n - k - 1;  // m = length of the reflector
-    if (wg == owner) {
-      const double* row = A + (size_t)lk * n;
-      double part = 0.0;
-      for (int j = k + 2 + tid; j < n; j += TT) part += row[j] * row[j];
-      const double xnorm2 = block_sum(part, s_red);
-      const double alpha = row[k + 1];
-      double tau, beta, scale;
-      if (xnorm2 == 0.0) {
-        tau = 0.0; beta = alpha; scale = 0.0;
-      } else {
-        beta = -copysign(sqrt(alpha * alpha + xnorm2), alpha);
-        tau = (beta - alpha) / beta;
-        scale = 1.0 / (alpha - beta);
-      }
+    // sl holds the current row k (entries j >= k): reflector of step k, identical in every workgroup
+    double tau, beta;
+    make_reflector(sl, k, n, sv, s_red, &tau, &beta);
+    if (wg == k % TW) {
       double* vk = p.V + (size_t)k * n;
-      for (int j = k + 1 + tid; j < n; j += TT) st_wt(&vk[j], (j == k + 1) ? 1.0 : row[j] * scale);
+      for (int j = k + 1 + tid; j < n; j += TT) vk[j] = sv[j];
       if (tid == 0) {
-        st_wt(&p.tau[k], tau);
-        p.d[k] = row[k];
+        p.tau[k] = tau;
+        p.d[k] = sl[k];
         p.e[k] = beta;
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-      if (tid == 0) __hip_atomic_store(&p.flags[0], k + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    // ---- hand-off 1: everyone takes the reflector -----------------------------------------
-    if (!wait_flag(&p.flags[0], k + 1, &p.flags[3], &s_abort)) return;
-    {
-      const double* vk = p.V + (size_t)k * n;
-      for (int j = k + 1 + tid; j < n; j += TT) sv[j] = ld_wt(&vk[j]);
-      if (tid == 0) s_tau = ld_wt(&p.tau[k]);
-    }
-    __syncthreads();
-    const double tau = s_tau;
-    if (tau == 0.0) continue;  // H = I: same decision in every workgroup
-
-    // ---- p = tau * A v on the local rows i > k ----------------------------------------------
+    // ---- p = tau * A v on the local rows i > k; the owner of row k+1 adds that row (pre-update) ----
     double* Pk = p.P + (size_t)(k & 1) * n;
-    for (int li = ty; li < RB; li += 32) {
-      const int gi = li * TW + wg;
-      if (gi > k && gi < n) {
-        const double* row = A + (size_t)li * n;
-        double acc = 0.0;
-        for (int j = k + 1 + tx; j < n; j += 32) acc = fma(row[j], sv[j], acc);
+    double* Lk = p.P + (size_t)(2 + (k & 1)) * n;
+    if (tau != 0.0) {
+      for (int li = ty; li < RB; li += 32) {
+        const int gi = li * TW + wg;
+        if (gi > k && gi < n) {
+          const double* row = A + (size_t)li * n;
+          double acc = 0.0;
+          for (int j = k + 1 + tx; j < n; j += 32) acc = fma(row[j], sv[j], acc);
 #pragma unroll
-        for (int off = 16; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
-        if (tx == 0) st_wt(&Pk[gi], tau * acc);
+          for (int off = 16; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+          if (tx == 0) st_wt(&Pk[gi], tau * acc);
+        }
       }
+    }
+    if (wg == (k + 1) % TW) {
+      const double* row = A + (size_t)((k + 1) / TW) * n;
+      for (int j = k + 1 + tid; j < n; j += TT) st_wt(&Lk[j], row[j]);
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(&p.flags[1 + (k & 1)], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    cnt_target[k & 1] += TW;
-    // ---- hand-off 2: everyone takes the whole p ----------------------------------------------
-    if (!wait_flag(&p.flags[1 + (k & 1)], cnt_target[k & 1], &p.flags[3], &s_abort)) return;
-    for (int j = k + 1 + tid; j < n; j += TT) sp[j] = ld_wt(&Pk[j]);
+    // one monotonic counter: nobody can arrive for hop h+1 before all 16 arrived for hop h, and the
+    // payload buffers alternate, so a fast workgroup never overwrites what a slow one still reads
+    if (tid == 0) __hip_atomic_fetch_add(&p.flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ++hop;
+    // ---- the hand-off ---------------------------------------------------------------------------
+    if (!wait_flag(&p.flags[1], hop * TW, &p.flags[3], &s_abort)) return;
+    for (int j = k + 1 + tid; j < n; j += TT) {
+      sl[j] = ld_wt(&Lk[j]);
+      if (tau != 0.0) sp[j] = ld_wt(&Pk[j]);
+    }
     __syncthreads();
+    if (tau == 0.0) continue;  // H = I: nothing to update, sl already is the next row
     double part = 0.0;
     for (int j = k + 1 + tid; j < n; j += TT) part += sp[j] * sv[j];
     const double alpha2 = -0.5 * tau * block_sum(part, s_red);
     for (int j = k + 1 + tid; j < n; j += TT) sw[j] = fma(alpha2, sv[j], sp[j]);
     __syncthreads();
-    // ---- A <- A - v w^T - w v^T on the local rows i > k ---------------------------------------
+    // ---- A <- A - v w^T - w v^T on the local rows i > k, and on the look-ahead copy of row k+1 ----
     for (int li = ty; li < RB; li += 32) {
       const int gi = li * TW + wg;
       if (gi > k && gi < n) {
@@ -169,17 +194,16 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
         for (int j = k + 1 + tx; j < n; j += 32) row[j] -= vi * sw[j] + wi * sv[j];
       }
     }
-    __syncthreads();
-    (void)m;
-  }
-  // trailing 2 x 2
-  if (n >= 2) {
-    const int k = n - 2;
-    if (wg == k % TW && tid == 0) {
-      const double* row = A + (size_t)(k / TW) * n;
-      p.d[k] = row[k];
-      p.e[k] = row[k + 1];
+    {
+      const double vi = sv[k + 1], wi = sw[k + 1];
+      for (int j = k + 1 + tid; j < n; j += TT) sl[j] -= vi * sw[j] + wi * sv[j];
     }
+    __syncthreads();
+  }
+  // trailing 2 x 2: sl holds row n-2 (entries n-2, n-1); row n-1 is with its owner
+  if (wg == (n - 2) % TW && tid == 0) {
+    p.d[n - 2] = sl[n - 2];
+    p.e[n - 2] = sl[n - 1];
   }
   if (wg == (n - 1) % TW && tid == 0) {
     p.d[n - 1] = A[(size_t)((n - 1) / TW) * n + (n - 1)];
@@ -188,12 +212,19 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
 }
 
 // number of eigenvalues of T smaller than x (Sturm count, dstebz recurrence)
+// 1/q by v_rcp_f64 and one Newton step (<= 1 ulp): the IEEE divide sequence is ~4x as long and the
+// count only has to be that of a matrix within eps of T
+__device__ __forceinline__ double fast_rcp(double q) {
+  const double r = __builtin_amdgcn_rcp(q);
+  return fma(fma(-q, r, 1.0), r, r);
+}
+
 __device__ __forceinline__ int sturm_count(const double* d, const double* e2, int n, double x, double pivmin) {
   double q = d[0] - x;
   if (fabs(q) < pivmin) q = -pivmin;
   int c = (q < 0.0);
   for (int i = 1; i < n; ++i) {
-    q = d[i] - x - e2[i - 1] / q;
+    q = fma(-e2[i - 1], fast_rcp(q), d[i] - x);
     if (fabs(q) < pivmin) q = -pivmin;
     c += (q < 0.0);
   }
@@ -295,49 +326,56 @@ __global__ __launch_bounds__(64) void symeig_vectors_kernel(const VecParams p) {
   const double tiny = 2.2e-16 * fmax(tnorm, 1e-300);
   __syncthreads();
   if (lane == 0) {
-    // P L U = T - lambda I with partial pivoting (dlagtf recurrences)
+    // P L U = T - lambda I with partial pivoting (dlagtf recurrences); a[] ends up holding 1/pivot
+    double ak = a[0];
     for (int k = 0; k + 1 < n; ++k) {
-      if (fabs(c[k]) <= fabs(a[k])) {
+      const double ck = c[k], bk = b[k], an = a[k + 1];
+      double piv_k, next;
+      if (fabs(ck) <= fabs(ak)) {
         piv[k] = 0;
-        const double ak = (a[k] == 0.0) ? tiny : a[k];
-        const double mult = c[k] / ak;
-        a[k + 1] -= mult * b[k];
+        piv_k = (fabs(ak) < tiny) ? copysign(tiny, ak == 0.0 ? 1.0 : ak) : ak;
+        const double mult = ck * fast_rcp(piv_k);
+        next = fma(-mult, bk, an);
         c[k] = mult;
       } else {
         piv[k] = 1;
-        const double mult = a[k] / c[k];
-        a[k] = c[k];
-        const double temp = a[k + 1];
-        a[k + 1] = b[k] - mult * temp;
+        const double mult = ak * fast_rcp(ck);
+        piv_k = ck;
+        next = fma(-mult, an, bk);
         if (k + 2 < n) {
-          d2[k] = b[k + 1];
-          b[k + 1] = -mult * d2[k];
+          const double t2 = b[k + 1];
+          d2[k] = t2;
+          b[k + 1] = -mult * t2;
         }
-        b[k] = temp;
+        b[k] = an;
         c[k] = mult;
       }
+      a[k] = fast_rcp(piv_k);
+      ak = next;
     }
-    for (int it = 0; it < 4; ++it) {
-      // forward: y = L^-1 P z
+    a[n - 1] = fast_rcp((fabs(ak) < tiny) ? copysign(tiny, ak == 0.0 ? 1.0 : ak) : ak);
+    for (int it = 0; it < 3; ++it) {
+      // forward: y = L^-1 P z (the running entry stays in a register)
+      double cur = z[0];
       for (int k = 0; k + 1 < n; ++k) {
+        const double nxt = z[k + 1], ck = c[k];
         if (piv[k]) {
-          const double tmp = z[k];
-          z[k] = z[k + 1];
-          z[k + 1] = tmp - c[k] * z[k];
+          z[k] = nxt;
+          cur = fma(-ck, nxt, cur);
         } else {
-          z[k + 1] -= c[k] * z[k];
+          z[k] = cur;
+          cur = fma(-ck, cur, nxt);
         }
       }
-      // backward: U x = y, tiny pivots perturbed (dlagts job = -1)
-      double zmax = 0.0;
+      z[n - 1] = cur;
+      // backward: U x = y with the reciprocal pivots
+      double z1 = 0.0, z2 = 0.0, zmax = 0.0;
       for (int k = n - 1; k >= 0; --k) {
-        double tmp = z[k];
-        if (k + 1 < n) tmp -= b[k] * z[k + 1];
-        if (k + 2 < n) tmp -= d2[k] * z[k + 2];
-        double ak = a[k];
-        if (fabs(ak) < tiny) ak = copysign(tiny, ak == 0.0 ? 1.0 : ak);
-        z[k] = tmp / ak;
-        zmax = fmax(zmax, fabs(z[k]));
+        const double zk = fma(-d2[k], z2, fma(-b[k], z1, z[k])) * a[k];
+        z[k] = zk;
+        zmax = fmax(zmax, fabs(zk));
+        z2 = z1;
+        z1 = zk;
       }
       const double sc = 1.0 / fmax(zmax, 1e-300);
       for (int k = 0; k < n; ++k) z[k] *= sc;
@@ -352,19 +390,44 @@ __global__ __launch_bounds__(64) void symeig_vectors_kernel(const VecParams p) {
   const double inv = 1.0 / sqrt(part);
   for (int i = lane; i < n; i += 64) z[i] *= inv;
   __syncthreads();
-  // x = Q z = H_0 H_1 ... H_{n-3} z : apply the reflectors from the last to the first
+  // x = Q z = H_0 H_1 ... H_{n-3} z : apply the reflectors from the last to the first; the next
+  // reflector's entries are fetched while the current one is applied (lane owns j = lane + 64 q)
+  constexpr int PER = NMAX / 64;
+  double zr[PER], vc[PER], vn[PER];
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int j = lane + 64 * q;
+    zr[q] = (j < n) ? z[j] : 0.0;
+  }
+  auto fetch = [&](int k, double (&dst)[PER]) {
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int j = lane + 64 * q;
+      dst[q] = (k >= 0 && j > k && j < n) ? p.V[(size_t)k * n + j] : 0.0;
+    }
+  };
+  fetch(n - 3, vc);
   for (int k = n - 3; k >= 0; --k) {
+    fetch(k - 1, vn);
     const double tk = p.tau[k];
-    if (tk == 0.0) continue;
-    const double* vk = p.V + (size_t)k * n;
     double dot = 0.0;
-    for (int j = k + 1 + lane; j < n; j += 64) dot = fma(vk[j], z[j], dot);
+#pragma unroll
+    for (int q = 0; q < PER; ++q) dot = fma(vc[q], zr[q], dot);
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
-    const double s = tk * dot;
-    for (int j = k + 1 + lane; j < n; j += 64) z[j] -= s * vk[j];
-    __syncthreads();
+    const double sdot = tk * dot;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      zr[q] = fma(-sdot, vc[q], zr[q]);
+      vc[q] = vn[q];
+    }
   }
+#pragma unroll
+  for (int q = 0; q < PER; ++q) {
+    const int j = lane + 64 * q;
+    if (j < n) z[j] = zr[q];
+  }
+  __syncthreads();
   for (int i = lane; i < n; i += 64) p.W[(size_t)i * p.k + t] = z[i];
 }
 
@@ -389,7 +452,7 @@ extern "C" int rt_sym_eig_values(rt_ctx* ctx, const double* G, int64_t n, double
   // composite arena: V (n*n) | P (2n) | tau | d | e | flags
   size_t off = 0;
   auto take = [&off](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
-  const size_t oV = take(sizeof(double) * n * n), oP = take(sizeof(double) * 2 * n), oT = take(sizeof(double) * n),
+  const size_t oV = take(sizeof(double) * n * n), oP = take(sizeof(double) * 4 * n), oT = take(sizeof(double) * n),
                oD = take(sizeof(double) * n), oE = take(sizeof(double) * n), oF = take(sizeof(int) * 8);
   void* base = nullptr;
   int rc = rt_scratch2(ctx, off, &base);
@@ -404,7 +467,7 @@ extern "C" int rt_sym_eig_values(rt_ctx* ctx, const double* G, int64_t n, double
   hipLaunchKernelGGL(symeig_init_kernel, dim3(1), dim3(256), 0, st, tp.flags, tp.tau, (int)n);
 
   const int RB = (int)((n + TW - 1) / TW);
-  const size_t lds = sizeof(double) * ((size_t)RB * n + 3 * n + 16);
+  const size_t lds = sizeof(double) * ((size_t)RB * n + 4 * n + 16);
   static bool attr_set = false;
   if (!attr_set) {
     RT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&symeig_tridiag_kernel),
