@@ -80,7 +80,11 @@ extern "C" int rt_project_csr_batched(rt_ctx* ctx, const int64_t* indptr, const 
   const long d_es = (data_layout == RT_COL_MAJOR) ? 1 : ld_data;  // stride between entries of one vector
   const long d_bs = (data_layout == RT_COL_MAJOR) ? ld_data : 1;  // stride between vectors
 
-  // chunk the modes so that the AV workspace stays <= ~2 GiB
+  {
+    const int frc = rt_project_fused(ctx, indptr, indices, data_batch, d_es, d_bs, B, N, V, ldv, r, AN_batch);
+    if (frc != RT_ERR_UNSUPPORTED) return frc;
+  }
+  // r > 128: unfused route.  Chunk the modes so that the AV workspace stays <= ~2 GiB
   long chunk = (long)((2ull << 30) / (sizeof(double) * (size_t)N * (size_t)r));
   if (chunk < 1) chunk = 1;
   if (chunk > B) chunk = B;

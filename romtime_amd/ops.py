@@ -152,6 +152,10 @@ def project_csr_batched(indptr, indices, data_batch: torch.Tensor, V: torch.Tens
     V = V.contiguous()
     data_batch, ld, lay = _layout(data_batch)
     nnz, B = data_batch.shape
+    if lay == ROW_MAJOR and B > 1:
+        # one HBM pass to make every value vector contiguous: a workgroup streams ONE vector, and in the
+        # (nnz x B) C order each 8-byte value would cost a 128-byte line
+        data_batch, ld, lay = transpose(data_batch).T, nnz, COL_MAJOR
     N = indptr.numel() - 1
     r = V.shape[1]
     AN = torch.empty((B, r, r), dtype=torch.float64, device=V.device)

@@ -123,7 +123,7 @@ def _penta(N, rng):
     return A
 
 
-@pytest.mark.parametrize("N,r", [(300, 8), (5000, 80), (2048, 33)])
+@pytest.mark.parametrize("N,r", [(300, 8), (5000, 80), (2048, 33), (40000, 128), (1234, 1), (3000, 140)])
 def test_project_csr(ops, N, r):
     rng = np.random.RandomState(N)
     A = _penta(N, rng)

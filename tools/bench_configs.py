@@ -136,7 +136,7 @@ def c5(nt=200, n_mu=32):
         u = oracle.reduced_solve(KNh, Vh.T @ f.cpu().numpy())
         Vh @ u
     cpu = (time.perf_counter() - t0) / 3
-    return dict(config=f"C5 online r=80 N=1e5 {n_mu} mu per batched step (unfused kernels)", ms_per_batched_step=ms,
+    return dict(config=f"C5 online r=80 N=1e5 {n_mu} mu per batched step (fused SpMM+MFMA projection)", ms_per_batched_step=ms,
                 reduced_steps_per_s=n_mu / ms * 1e3, TFs=flops / ms / 1e9, mfma_frac=flops / ms / 1e9 / MFMA,
                 cpu_s_per_step=cpu, cpu_steps_per_s=1.0 / cpu)
 
