@@ -158,9 +158,15 @@ def main():
         alg_flops = n_local * n * (n + 1)           # symmetric Gram: N n (n+1) flops
         alg_bytes = 8 * (n_local * n + n * n)       # read X once + write G
         achieved = alg_flops / (k_ms * 1e-3) / 1e12
+        traffic = None  # HBM bytes per Gram from the committed PMC passes of this same command (profiles/)
+        tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "gram_traffic.json")
+        if world == 1 and (n_h, n) == (N_H, N_S) and os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get("hbm_bytes_per_gram")
         roofline = dict(bound="mfma", achieved=achieved, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=achieved / FP64_MFMA_PEAK_TFLOPS, traffic=None,
-                        kernel="gemm_f64_mfma_kernel (Gram, symmetric tiles)", kernel_ms=k_ms,
+                        frac=achieved / FP64_MFMA_PEAK_TFLOPS, traffic=traffic,
+                        kernel="gram128_kernel<KC,false> + gram128_kernel<KC,true> (off-diagonal + diagonal tiles "
+                               "of one Gram, one event pair around both launches)", kernel_ms=k_ms,
+                        algorithmic_flops=alg_flops, algorithmic_bytes=alg_bytes,
                         hbm_frac=alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         note="FP64 Gram at n=512 is 64 flop/B: matrix-core bound, not HBM bound")
         line = {
