@@ -121,6 +121,28 @@ int rt_project_csr_batched(rt_ctx* ctx, const int64_t* indptr, const int64_t* in
  * info (B device ints, may be NULL): 0, or RT_WARN_SINGULAR. r <= 128. */
 int rt_dense_solve_batched(rt_ctx* ctx, double* K, double* rhs, int64_t r, int64_t B, int* info);
 
+/* ---- online sweep (RomConstructor*.solve, rom/rom.py:430-555, :877-929) on the device --------- */
+typedef struct {
+  int64_t N, nnz, r, n_mu, nt;   /* DoFs, pattern nonzeros, reduced size (<= 128), parameter points, time steps */
+  double dt;
+  int bdf2;                      /* 1: BDF2 with u* = 2 u_h - u_h^{n-1} (fom.BDF_SCHEME == "2"), 0: BDF1 */
+  const int64_t* indptr;         /* CSR pattern shared by every operator (device) */
+  const int64_t* indices;
+  const double* V;               /* N x r row-major reduced basis */
+  const double* mass_values;     /* nnz: mass matrix values */
+  int64_t n_terms;               /* affine operator terms */
+  const double* term_values;     /* n_terms x nnz: value vector of each term */
+  const double* term_coef;       /* nt x n_mu x n_terms: theta_q(mu, t) of step s at [s][mu][q] */
+  const double* tril_values;     /* nnz or NULL: T of the state-dependent term diag(u*) T (trilinear, rom.py:931-952) */
+  int64_t n_rhs;
+  const double* rhs_terms;       /* n_rhs x N: source vectors (lifting / forcing) */
+  const double* rhs_coef;        /* nt x n_mu x n_rhs */
+} rt_sweep_desc;
+/* K_N = bdf M_N + dt V^T(sum_q theta_q A_q + diag(u*) T)V,  b_N = M_N(2u^n - u^{n-1}/2) + dt V^T f,
+ * u^{n+1} = K_N^-1 b_N, for all n_mu parameter points per step, nt steps, zero initial condition
+ * (rom.py:451-453).  uN_out: n_mu x nt x r (device).  Everything stays on the ctx stream. */
+int rt_rom_bdf_sweep(rt_ctx* ctx, const rt_sweep_desc* desc, double* uN_out);
+
 /* ---- small symmetric eigenproblem of the Gram matrix, on the device (3 <= n <= 512) ----------- */
 /* Householder tridiagonalisation (16 workgroups, matrix resident in LDS) + Sturm multisection:
  * lam (n, device) = all eigenvalues of the symmetric G (n x n row-major, not modified), DESCENDING.

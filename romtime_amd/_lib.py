@@ -42,12 +42,24 @@ SIGNATURES = {
     "rt_project_csr": (_int, [_p, _p, _p, _p, _i64, _p, _i64, _i64, _p]),
     "rt_project_csr_batched": (_int, [_p, _p, _p, _p, _i64, _int, _i64, _i64, _p, _i64, _i64, _p]),
     "rt_dense_solve_batched": (_int, [_p, _p, _p, _i64, _i64, _p]),
+    "rt_rom_bdf_sweep": (_int, [_p, _p, _p]),
     "rt_sym_eig_values": (_int, [_p, _p, _i64, _p, _p]),
     "rt_sym_eig_vectors": (_int, [_p, _i64, _i64, _p, _p]),
     "rt_host_jacobi_eigh": (_int, [_p, _i64, _p, _p, _int, C.POINTER(_int)]),
     "rt_bench_mfma_f64": (_int, [_p, _int, C.POINTER(C.c_double)]),
     "rt_bench_copy": (_int, [_p, _p, _p, _i64, _int, C.POINTER(C.c_double)]),
 }
+
+
+
+class SweepDesc(C.Structure):
+    """rt_sweep_desc of include/romtime_hip.h."""
+
+    _fields_ = [("N", _i64), ("nnz", _i64), ("r", _i64), ("n_mu", _i64), ("nt", _i64), ("dt", C.c_double),
+                ("bdf2", _int), ("indptr", _p), ("indices", _p), ("V", _p), ("mass_values", _p), ("n_terms", _i64),
+                ("term_values", _p), ("term_coef", _p), ("tril_values", _p), ("n_rhs", _i64), ("rhs_terms", _p),
+                ("rhs_coef", _p)]
+
 
 _lib = None
 _lock = threading.Lock()

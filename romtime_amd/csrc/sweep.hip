@@ -1,0 +1,131 @@
+// Online reduced sweep on the device (RomConstructor*.solve, rom.py:430-555 with the direct-path
+// assemble_system / assemble_system_rhs of rom.py:877-929), for n_mu parameter points at once.
+//
+// Per time step, all on the ctx stream, nothing returns to the host:
+//   K_N[b] = V^T (bdf M + dt (sum_q theta_q(mu_b, t) A_q + diag(u*_b) T)) V   fused projection, entry values
+//                                                                           generated on the fly
+//   b_N[b] = M_N (2 u^n - u^{n-1}/2) + dt sum_f phi_f(mu_b, t) (V^T f_f)     (BDF2; M_N u^n + ... for BDF1 / step 0)
+//   u^{n+1}[b] = K_N[b]^-1 b_N[b]                                            batched pivoted LU in LDS
+//   u_h[b] = V u^{n+1}[b],   u* = 2 u_h - u_h^{n-1}                          next step's trilinear state
+// The operators are affine in precomputed value vectors on one CSR pattern (the form MDEIM itself
+// produces, and what a closed-form 1-D assembly yields); the state-dependent term is diag(u*) T.
+#include "common.h"
+
+namespace {
+
+__global__ void sweep_rows_kernel(const long* __restrict__ indptr, long N, int* __restrict__ row_of) {
+  const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= N) return;
+  for (long e = indptr[row]; e < indptr[row + 1]; ++e) row_of[e] = (int)row;
+}
+
+// rhs[b] = M_N (c0 u_n[b] + c1 u_nm1[b]) + dt * sum_f rcoef[b][f] * fN[f]
+__global__ void sweep_rhs_kernel(const double* __restrict__ MN, const double* __restrict__ un,
+                                 const double* __restrict__ unm1, double c0, double c1, double dt,
+                                 const double* __restrict__ rcoef, const double* __restrict__ fN, int F, int r,
+                                 double* __restrict__ rhs) {
+  extern __shared__ double su[];
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (t < r) su[t] = c0 * un[(long)b * r + t] + c1 * unm1[(long)b * r + t];
+  __syncthreads();
+  if (t < r) {
+    double acc = 0.0;
+    for (int j = 0; j < r; ++j) acc = fma(MN[(long)t * r + j], su[j], acc);
+    double f = 0.0;
+    for (int q = 0; q < F; ++q) f = fma(rcoef[(long)b * F + q], fN[(long)q * r + t], f);
+    rhs[(long)b * r + t] = fma(dt, f, acc);
+  }
+}
+
+__global__ void sweep_store_kernel(const double* __restrict__ x, double* __restrict__ un, double* __restrict__ unm1,
+                                   double* __restrict__ out, long step, long nt, int r, int keep_prev) {
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (t < r) {
+    const double v = x[(long)b * r + t];
+    if (keep_prev) unm1[(long)b * r + t] = un[(long)b * r + t];
+    un[(long)b * r + t] = v;
+    out[((long)b * nt + step) * r + t] = v;
+  }
+}
+
+}  // namespace
+
+extern "C" int rt_rom_bdf_sweep(rt_ctx* ctx, const rt_sweep_desc* d, double* uN_out) {
+  if (!ctx) return RT_ERR_ARG;
+  RT_ARG_CHECK(ctx, d && uN_out);
+  RT_ARG_CHECK(ctx, d->N >= 1 && d->nnz >= 1 && d->r >= 1 && d->r <= 128 && d->n_mu >= 1 && d->nt >= 1);
+  RT_ARG_CHECK(ctx, d->indptr && d->indices && d->V && d->mass_values && d->n_terms >= 0 && d->n_rhs >= 0);
+  RT_ARG_CHECK(ctx, (d->n_terms == 0 || (d->term_values && d->term_coef)) && (d->n_rhs == 0 || (d->rhs_terms && d->rhs_coef)));
+  const long N = d->N, nnz = d->nnz, r = d->r, B = d->n_mu, nt = d->nt;
+  const int Q = (int)d->n_terms, F = (int)d->n_rhs;
+  hipStream_t st = ctx->stream;
+
+  // workspace (composite arena)
+  size_t off = 0;
+  auto take = [&off](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  const size_t oRow = take(sizeof(int) * nnz), oMN = take(sizeof(double) * r * r), oFN = take(sizeof(double) * (F ? F : 1) * r),
+               oKN = take(sizeof(double) * B * r * r), oRhs = take(sizeof(double) * B * r), oUn = take(sizeof(double) * B * r),
+               oUm = take(sizeof(double) * B * r), oUh = take(sizeof(double) * B * N), oUp = take(sizeof(double) * B * N),
+               oXT = take(sizeof(double) * r * B), oInfo = take(sizeof(int) * B);
+  void* base = nullptr;
+  int rc = rt_scratch2(ctx, off, &base);
+  if (rc != RT_OK) return rc;
+  char* b8 = static_cast<char*>(base);
+  int* row_of = reinterpret_cast<int*>(b8 + oRow);
+  double* MN = reinterpret_cast<double*>(b8 + oMN);
+  double* fN = reinterpret_cast<double*>(b8 + oFN);
+  double* KN = reinterpret_cast<double*>(b8 + oKN);
+  double* rhs = reinterpret_cast<double*>(b8 + oRhs);
+  double* un = reinterpret_cast<double*>(b8 + oUn);
+  double* unm1 = reinterpret_cast<double*>(b8 + oUm);
+  double* uh = reinterpret_cast<double*>(b8 + oUh);
+  double* uhp = reinterpret_cast<double*>(b8 + oUp);
+  double* xT = reinterpret_cast<double*>(b8 + oXT);
+  int* info = reinterpret_cast<int*>(b8 + oInfo);
+
+  RT_HIP_CHECK(ctx, hipMemsetAsync(un, 0, sizeof(double) * B * r, st));
+  RT_HIP_CHECK(ctx, hipMemsetAsync(unm1, 0, sizeof(double) * B * r, st));
+  RT_HIP_CHECK(ctx, hipMemsetAsync(uh, 0, sizeof(double) * B * N, st));
+  RT_HIP_CHECK(ctx, hipMemsetAsync(uhp, 0, sizeof(double) * B * N, st));
+  hipLaunchKernelGGL(sweep_rows_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st,
+                     reinterpret_cast<const long*>(d->indptr), N, row_of);
+  RT_HIP_CHECK(ctx, hipGetLastError());
+  // M_N = V^T M V and f_N[f] = V^T f_f, once
+  rc = rt_project_fused_ex(ctx, d->indptr, d->indices, d->mass_values, 1, 0, 1, N, d->V, r, r, MN, nullptr);
+  if (rc != RT_OK) return rc;
+  if (F) {
+    // rhs_terms is F x N (each vector contiguous): A(k, i) = V[k][i], B(k, f) = rhs_terms[f][k]
+    rc = rt_gemm_strided(ctx, d->rhs_terms, 1, N, d->V, r, 1, N, F, r, fN, r, 1, false, true);
+    if (rc != RT_OK) return rc;
+  }
+
+  ProjAffine aff;
+  aff.mass = d->mass_values; aff.terms = d->term_values; aff.tril = d->tril_values; aff.row_of = row_of;
+  aff.nnz = nnz; aff.ld_u = N; aff.n_terms = Q; aff.dt = d->dt;
+  for (long step = 0; step < nt; ++step) {
+    const bool second = d->bdf2 && step > 0;
+    aff.bdf = second ? 1.5 : 1.0;
+    aff.coef = Q ? d->term_coef + step * B * Q : nullptr;
+    aff.uh = uh; aff.uh_prev = uhp; aff.extrapolate = d->bdf2 ? 1 : 0;
+    rc = rt_project_fused_ex(ctx, d->indptr, d->indices, d->mass_values, 1, 0, B, N, d->V, r, r, KN, &aff);
+    if (rc != RT_OK) return rc;
+    const double c0 = d->bdf2 ? 2.0 : 1.0, c1 = d->bdf2 ? -0.5 : 0.0;  // u^{n-1} = 0 at step 0 reproduces BDF1
+    // reference: step 0 of a BDF2 run uses M_N (2 u^0 - u^{-1}/2) with both zero (rom.py:451-458,921-924)
+    hipLaunchKernelGGL(sweep_rhs_kernel, dim3((unsigned)B), dim3(128), sizeof(double) * r, st, MN, un, unm1, c0, c1,
+                       d->dt, F ? d->rhs_coef + step * B * F : nullptr, fN, F, (int)r, rhs);
+    RT_HIP_CHECK(ctx, hipGetLastError());
+    rc = rt_dense_solve_batched(ctx, KN, rhs, r, B, info);
+    if (rc != RT_OK) return rc;
+    hipLaunchKernelGGL(sweep_store_kernel, dim3((unsigned)B), dim3(128), 0, st, rhs, un, unm1, uN_out, step, nt, (int)r,
+                       d->bdf2 ? 1 : 0);
+    RT_HIP_CHECK(ctx, hipGetLastError());
+    // u_h <- V u_N for every mu, stored [mu][N]; the previous u_h becomes u_h^{n-1}
+    double* tmp = uhp; uhp = uh; uh = tmp;
+    // Y (N x B, column-major ld N) = V (N x r) * xT (r x B); xT[j][b] = un[b][j]
+    rc = rt_transpose(ctx, un, B, r, r, xT, B);
+    if (rc != RT_OK) return rc;
+    rc = rt_gemm_nn(ctx, d->V, r, RT_ROW_MAJOR, xT, B, N, r, B, uh, N, RT_COL_MAJOR);
+    if (rc != RT_OK) return rc;
+  }
+  return RT_OK;
+}

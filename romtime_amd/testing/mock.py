@@ -206,3 +206,98 @@ class MockBurgers(MockSolver):
         fa, fb = gdot[:-1], gdot[1:]
         elem = np.stack([h / 6.0 * (2.0 * fa + fb), h / 6.0 * (fa + 2.0 * fb)], axis=1)
         return self._assemble_vector(elem, entries)
+
+
+class AffineBurgers:
+    """Synthetic Burgers-type FOM whose operators are affine in fixed value vectors on ONE CSR pattern
+    (pentadiagonal), the form the device sweep (rt_rom_bdf_sweep) consumes:
+
+        A(mu)      = alpha          * A0           C(mu, t) = beta  * sin(omega t) * C0
+        N(u)       = diag(u) T                     Nhat(mu, t) = delta * cos(omega t) * N0
+        f_g(mu, t) = sin(omega t) f0 + delta t f1
+
+    It serves the same ``assemble_*`` callbacks as the FEniCS solvers (rom.py:877-929 call sites), so the
+    reference loop / the oracle / RomConstructorNonlinear can run on it, and ``descriptor`` lays the same
+    data out for the device.  ``mu`` keys: alpha, beta, delta, omega.  Lifting function g_h = 0."""
+
+    RUNTIME_PROCESS = False
+    exact_solution = None
+
+    def __init__(self, N, nt, dt, bdf2=True, seed=0):
+        rng = np.random.RandomState(seed)
+        self.Nh, self.nt, self._dt, self.bdf2 = int(N), int(nt), float(dt), bool(bdf2)
+        self.BDF_SCHEME = "2" if bdf2 else "1"
+        self.domain = {"nt": self.nt, "T": self.nt * self._dt, "nx": self.Nh - 1, "L0": 1.0}
+        self.is_setup = True
+        offs = [-2, -1, 0, 1, 2]
+        rows = np.concatenate([np.arange(max(0, -o), min(N, N - o)) for o in offs])
+        cols = np.concatenate([np.arange(max(0, -o), min(N, N - o)) + o for o in offs])
+        pat = csr_matrix((np.ones(rows.size), (rows, cols)), shape=(N, N))
+        pat.sort_indices()
+        self.indptr, self.indices = pat.indptr.astype(np.int64), pat.indices.astype(np.int64)
+        rr = np.repeat(np.arange(N), np.diff(self.indptr))
+        off = self.indices - rr
+        x = (rr + 0.5) / N
+        self.mass = np.where(off == 0, 1.0, np.where(np.abs(off) == 1, 0.15, 0.02)) * (1.0 + 0.1 * np.sin(3 * x))
+        self.A0 = np.where(off == 0, 2.5, np.where(np.abs(off) == 1, -1.0, -0.25)) * (1.0 + 0.3 * x) * 40.0
+        self.C0 = np.sign(off) * (1.0 / np.maximum(np.abs(off), 1)) * (1.0 + 0.2 * np.cos(2 * x)) * 3.0
+        self.N0 = (0.3 * rng.standard_normal(rows.size) + np.where(off == 0, 1.0, 0.0)) * 2.0
+        self.T = np.sign(off) * (0.5 + 0.1 * rng.standard_normal(rows.size)) * 5.0
+        xs = (np.arange(N) + 0.5) / N
+        self.f = np.stack([np.sin(np.pi * xs), xs * (1 - xs) * 4.0])
+
+    def setup(self):
+        pass
+
+    def update_parametrization(self, mu):
+        self.mu = dict(mu)
+
+    @property
+    def dt(self):
+        return self._dt
+
+    def _csr(self, vals):
+        return csr_matrix((vals, self.indices, self.indptr), shape=(self.Nh, self.Nh))
+
+    # coefficient functions (shared by the host callbacks and the device descriptor)
+    @staticmethod
+    def thetas(mu, t):
+        return np.array([mu["alpha"], mu["beta"] * np.sin(mu["omega"] * t), mu["delta"] * np.cos(mu["omega"] * t)])
+
+    @staticmethod
+    def phis(mu, t):
+        return np.array([np.sin(mu["omega"] * t), mu["delta"] * t])
+
+    def assemble_mass(self, mu, t):
+        return self._csr(self.mass)
+
+    def assemble_stiffness(self, mu, t):
+        return self._csr(self.thetas(mu, t)[0] * self.A0)
+
+    def assemble_convection(self, mu, t):
+        return self._csr(self.thetas(mu, t)[1] * self.C0)
+
+    def assemble_nonlinear_lifting(self, mu, t):
+        return self._csr(self.thetas(mu, t)[2] * self.N0)
+
+    def assemble_trilinear(self, mu, t, u_n):
+        rr = np.repeat(np.arange(self.Nh), np.diff(self.indptr))
+        return self._csr(np.asarray(u_n)[rr] * self.T)
+
+    def assemble_lifting(self, mu, t):
+        return self.phis(mu, t) @ self.f
+
+    def lifting(self, mu, t):
+        return np.zeros(self.Nh)
+
+    def x_at(self, mu, t):
+        return np.linspace(0.0, 1.0, self.Nh)
+
+    def descriptor(self, mus):
+        """Arrays for romtime_amd.sweep.rom_bdf_sweep: term values (3 x nnz), coefficients per step/mu."""
+        ts = self._dt * np.arange(1, self.nt + 1)
+        term_coef = np.array([[self.thetas(mu, t) for mu in mus] for t in ts])  # nt x n_mu x 3
+        rhs_coef = np.array([[self.phis(mu, t) for mu in mus] for t in ts])     # nt x n_mu x 2
+        return dict(indptr=self.indptr, indices=self.indices, mass=self.mass,
+                    terms=np.stack([self.A0, self.C0, self.N0]), term_coef=term_coef, tril=self.T,
+                    rhs_terms=self.f, rhs_coef=rhs_coef, dt=self._dt, bdf2=self.bdf2)

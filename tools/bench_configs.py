@@ -145,7 +145,41 @@ def c5(nt=200, n_mu=32):
                 cpu_s_per_step=cpu, cpu_steps_per_s=1.0 / cpu)
 
 
+def c5sweep(nt=200, n_mu=32, N=100_000, r=80):
+    """Config 5 as a device-resident sweep (rt_rom_bdf_sweep): nt BDF2 steps x n_mu parameter points."""
+    from romtime_amd.sweep import rom_bdf_sweep
+    from romtime_amd.testing.mock import AffineBurgers
+
+    fom = AffineBurgers(N=N, nt=nt, dt=1e-4, bdf2=True, seed=5)
+    xs = (np.arange(N) + 0.5) / N
+    rng = np.random.RandomState(1)
+    V, _ = np.linalg.qr(np.stack([np.sin((k + 1) * np.pi * xs) for k in range(r)], axis=1) + 1e-3 * rng.standard_normal((N, r)))
+    mus = [dict(alpha=0.5 + 0.02 * i, beta=1.0 - 0.01 * i, delta=0.3 + 0.005 * i, omega=7.0 + 0.1 * i) for i in range(n_mu)]
+    d = fom.descriptor(mus)
+    args = [ops.to_device(V), d["indptr"], d["indices"], ops.to_device(d["mass"]), ops.to_device(d["terms"]),
+            ops.to_device(d["term_coef"]), ops.to_device(d["tril"]), ops.to_device(d["rhs_terms"]),
+            ops.to_device(d["rhs_coef"]), d["dt"]]
+    rom_bdf_sweep(*args, bdf2=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    uN = rom_bdf_sweep(*args, bdf2=True)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    nnz = d["mass"].size
+    flops = nt * n_mu * (2.0 * nnz * r + 2.0 * N * r * r)
+    # oracle: the reference loop (5 separate projections per step, exact dense solve) for one mu, 3 steps
+    small = AffineBurgers(N=N, nt=3, dt=1e-4, bdf2=True, seed=5)
+    t0 = time.perf_counter()
+    ref, _ = oracle.rom_solve_nonlinear(small, V, mus[0], solver=np.linalg.solve)
+    cpu = (time.perf_counter() - t0) / 3
+    err = np.linalg.norm(uN[0, :3].cpu().numpy().T - ref) / np.linalg.norm(ref)
+    return dict(config=f"C5 online sweep r={r} N={N} {n_mu} mu x {nt} BDF2 steps on device (full config: 1e4 steps)",
+                wall_s=wall, ms_per_step_all_mu=1e3 * wall / nt, reduced_steps_per_s=nt * n_mu / wall,
+                TFs=flops / wall / 1e12, mfma_frac=flops / wall / 1e12 / MFMA, cpu_s_per_reduced_step=cpu,
+                cpu_reduced_steps_per_s=1.0 / cpu, first3_rel_err_vs_oracle=float(err))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["c2", "c4", "c5"]
+    which = sys.argv[1:] or ["c2", "c4", "c5", "c5sweep"]
     for w in which:
-        print(json.dumps({"c2": c2, "c4": c4, "c5": c5}[w]()), flush=True)
+        print(json.dumps({"c2": c2, "c4": c4, "c5": c5, "c5sweep": c5sweep}[w]()), flush=True)
