@@ -55,24 +55,7 @@ int rt_gemm_strided(rt_ctx* ctx, const double* A, int64_t a_ks, int64_t a_ms, co
 // Specialised Gram kernel (gram_mfma.hip); RT_ERR_UNSUPPORTED means "use rt_gemm_strided".
 int rt_gram128(rt_ctx* ctx, const double* X, int64_t ks, int64_t ms, int64_t K, int64_t n, double* G);
 
-// On-the-fly entry values for the online sweep: value(b, e) = bdf*mass[e] + dt*(sum_q coef[b][q]*terms[q][e]
-// + u*(b, row_of[e]) * tril[e]),  u* = 2 uh - uh_prev (extrapolate) or uh.
-struct ProjAffine {
-  const double* mass = nullptr;
-  const double* terms = nullptr;   // n_terms x nnz
-  const double* coef = nullptr;    // B x n_terms (this step)
-  const double* tril = nullptr;    // nnz or nullptr
-  const int* row_of = nullptr;     // nnz: row of every entry
-  const double* uh = nullptr;      // B x ld_u
-  const double* uh_prev = nullptr;
-  long nnz = 0, ld_u = 0;
-  int n_terms = 0, extrapolate = 0;
-  double bdf = 1.0, dt = 0.0;
-};
-
 // Fused SpMM + V^T(.) projection (project_fused.hip); RT_ERR_UNSUPPORTED for r > 128.
-int rt_project_fused_ex(rt_ctx* ctx, const int64_t* indptr, const int64_t* indices, const double* data, int64_t d_es,
-                        int64_t d_bs, int64_t B, int64_t N, const double* V, int64_t ldv, int64_t r, double* AN,
-                        const ProjAffine* aff);
+
 int rt_project_fused(rt_ctx* ctx, const int64_t* indptr, const int64_t* indices, const double* data, int64_t d_es,
                      int64_t d_bs, int64_t B, int64_t N, const double* V, int64_t ldv, int64_t r, double* AN);

@@ -34,24 +34,7 @@ struct ProjParams {
   long N, k_per_split;
   int r, B, S, tr, stride;
   const int* win;      // [2 * stages]: column window (lo, hi) of every 16-row stage, hi = -1: not windowed
-  ProjAffine aff;      // aff.mass != nullptr: entry values are generated on the fly (online sweep)
 };
-
-// value of entry e for batch member b
-__device__ __forceinline__ double entry_value(const ProjParams& p, const double* dat, int b, long e) {
-  if (p.aff.mass == nullptr) return dat[e * p.d_es];
-  const ProjAffine& a = p.aff;
-  double s = 0.0;
-  const double* cf = a.coef + (long)b * a.n_terms;
-  for (int q = 0; q < a.n_terms; ++q) s = fma(cf[q], a.terms[(long)q * a.nnz + e], s);
-  if (a.tril) {
-    const long row = a.row_of[e];
-    const double u = a.uh[(long)b * a.ld_u + row];
-    const double us = a.extrapolate ? 2.0 * u - a.uh_prev[(long)b * a.ld_u + row] : u;
-    s = fma(us, a.tril[e], s);
-  }
-  return fma(a.dt, s, a.bdf * a.mass[e]);
-}
 
 constexpr int WROWS = 32;     // V rows kept in LDS per stage (banded FE operators touch ~PK + 2*bandwidth)
 constexpr int EMAX = PT;      // entries of one stage staged through LDS (one per thread)
@@ -125,7 +108,7 @@ __global__ __launch_bounds__(PT, PACC <= 4 ? 4 : 2) void project_fused_kernel(co
     if (n_hi >= 0) {
       const long e = p.indptr[k0] + tid;
       const bool v = e < p.indptr[k1];
-      vreg = v ? entry_value(p, dat, b, e) : 0.0;
+      vreg = v ? dat[e * p.d_es] : 0.0;
       creg = v ? (int)p.indices[e] - n_lo : 0;
     }
   };
@@ -169,7 +152,7 @@ __global__ __launch_bounds__(PT, PACC <= 4 ? 4 : 2) void project_fused_kernel(co
           }
         } else {
           for (long e = e0; e < e1; ++e) {
-            const double a = entry_value(p, dat, b, e);
+            const double a = dat[e * p.d_es];
             const double* vr = p.V + p.indices[e] * p.ldv;
             if (jg < r) o0 = fma(a, vr[jg], o0);
             if (jg + 32 < r) o1 = fma(a, vr[jg + 32], o1);
@@ -234,19 +217,12 @@ __global__ void project_reduce_kernel(const double* __restrict__ slab, int S, lo
 // Returns RT_ERR_UNSUPPORTED for r > 128 (the caller then uses the unfused path).
 int rt_project_fused(rt_ctx* ctx, const int64_t* indptr, const int64_t* indices, const double* data, int64_t d_es,
                      int64_t d_bs, int64_t B, int64_t N, const double* V, int64_t ldv, int64_t r, double* AN) {
-  return rt_project_fused_ex(ctx, indptr, indices, data, d_es, d_bs, B, N, V, ldv, r, AN, nullptr);
-}
-
-int rt_project_fused_ex(rt_ctx* ctx, const int64_t* indptr, const int64_t* indices, const double* data, int64_t d_es,
-                        int64_t d_bs, int64_t B, int64_t N, const double* V, int64_t ldv, int64_t r, double* AN,
-                        const ProjAffine* aff) {
   if (r > RMAX) return RT_ERR_UNSUPPORTED;
   ProjParams p;
   p.indptr = reinterpret_cast<const long*>(indptr);
   p.indices = reinterpret_cast<const long*>(indices);
   p.data = data; p.d_es = d_es; p.d_bs = d_bs;
   p.V = V; p.ldv = ldv; p.N = N; p.r = (int)r; p.B = (int)B;
-  if (aff) p.aff = *aff; else p.aff = ProjAffine{};
   p.tr = (int)((r + 15) / 16);
   const int rp = p.tr * 16;
   p.stride = ((rp + 31) / 32) * 32 + 16;  // == 16 (mod 32): conflict-free ds_read_b64 of the MFMA operands

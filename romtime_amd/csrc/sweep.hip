@@ -2,8 +2,8 @@
 // assemble_system / assemble_system_rhs of rom.py:877-929), for n_mu parameter points at once.
 //
 // Per time step, all on the ctx stream, nothing returns to the host:
-//   K_N[b] = V^T (bdf M + dt (sum_q theta_q(mu_b, t) A_q + diag(u*_b) T)) V   fused projection, entry values
-//                                                                           generated on the fly
+//   k[b]   = bdf M + dt (sum_q theta_q(mu_b, t) A_q + diag(u*_b) T)           value vectors of the step (one pass)
+//   K_N[b] = V^T (A[k[b]] V)                                                  fused SpMM + MFMA projection
 //   b_N[b] = M_N (2 u^n - u^{n-1}/2) + dt sum_f phi_f(mu_b, t) (V^T f_f)     (BDF2; M_N u^n + ... for BDF1 / step 0)
 //   u^{n+1}[b] = K_N[b]^-1 b_N[b]                                            batched pivoted LU in LDS
 //   u_h[b] = V u^{n+1}[b],   u* = 2 u_h - u_h^{n-1}                          next step's trilinear state
@@ -17,6 +17,26 @@ __global__ void sweep_rows_kernel(const long* __restrict__ indptr, long N, int* 
   const long row = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (row >= N) return;
   for (long e = indptr[row]; e < indptr[row + 1]; ++e) row_of[e] = (int)row;
+}
+
+// kval[b][e] = bdf*mass[e] + dt*(sum_q coef[b][q]*terms[q][e] + u*(b, row_of[e])*tril[e]),  u* = 2 uh - uh_prev
+__global__ void sweep_values_kernel(const double* __restrict__ mass, const double* __restrict__ terms, int Q,
+                                    const double* __restrict__ coef, const double* __restrict__ tril,
+                                    const int* __restrict__ row_of, const double* __restrict__ uh,
+                                    const double* __restrict__ uhp, int extrapolate, long nnz, long N, double bdf,
+                                    double dt, double* __restrict__ kval) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (e >= nnz) return;
+  double s = 0.0;
+  for (int q = 0; q < Q; ++q) s = fma(coef[(long)b * Q + q], terms[(long)q * nnz + e], s);
+  if (tril) {
+    const long row = row_of[e];
+    const double u = uh[(long)b * N + row];
+    const double us = extrapolate ? 2.0 * u - uhp[(long)b * N + row] : u;
+    s = fma(us, tril[e], s);
+  }
+  kval[(long)b * nnz + e] = fma(dt, s, bdf * mass[e]);
 }
 
 // rhs[b] = M_N (c0 u_n[b] + c1 u_nm1[b]) + dt * sum_f rcoef[b][f] * fN[f]
@@ -66,7 +86,8 @@ extern "C" int rt_rom_bdf_sweep(rt_ctx* ctx, const rt_sweep_desc* d, double* uN_
   const size_t oRow = take(sizeof(int) * nnz), oMN = take(sizeof(double) * r * r), oFN = take(sizeof(double) * (F ? F : 1) * r),
                oKN = take(sizeof(double) * B * r * r), oRhs = take(sizeof(double) * B * r), oUn = take(sizeof(double) * B * r),
                oUm = take(sizeof(double) * B * r), oUh = take(sizeof(double) * B * N), oUp = take(sizeof(double) * B * N),
-               oXT = take(sizeof(double) * r * B), oInfo = take(sizeof(int) * B);
+               oXT = take(sizeof(double) * r * B), oInfo = take(sizeof(int) * B),
+               oKv = take(sizeof(double) * B * nnz);
   void* base = nullptr;
   int rc = rt_scratch2(ctx, off, &base);
   if (rc != RT_OK) return rc;
@@ -82,6 +103,7 @@ extern "C" int rt_rom_bdf_sweep(rt_ctx* ctx, const rt_sweep_desc* d, double* uN_
   double* uhp = reinterpret_cast<double*>(b8 + oUp);
   double* xT = reinterpret_cast<double*>(b8 + oXT);
   int* info = reinterpret_cast<int*>(b8 + oInfo);
+  double* kval = reinterpret_cast<double*>(b8 + oKv);
 
   RT_HIP_CHECK(ctx, hipMemsetAsync(un, 0, sizeof(double) * B * r, st));
   RT_HIP_CHECK(ctx, hipMemsetAsync(unm1, 0, sizeof(double) * B * r, st));
@@ -91,7 +113,7 @@ extern "C" int rt_rom_bdf_sweep(rt_ctx* ctx, const rt_sweep_desc* d, double* uN_
                      reinterpret_cast<const long*>(d->indptr), N, row_of);
   RT_HIP_CHECK(ctx, hipGetLastError());
   // M_N = V^T M V and f_N[f] = V^T f_f, once
-  rc = rt_project_fused_ex(ctx, d->indptr, d->indices, d->mass_values, 1, 0, 1, N, d->V, r, r, MN, nullptr);
+  rc = rt_project_fused(ctx, d->indptr, d->indices, d->mass_values, 1, 0, 1, N, d->V, r, r, MN);
   if (rc != RT_OK) return rc;
   if (F) {
     // rhs_terms is F x N (each vector contiguous): A(k, i) = V[k][i], B(k, f) = rhs_terms[f][k]
@@ -99,15 +121,14 @@ extern "C" int rt_rom_bdf_sweep(rt_ctx* ctx, const rt_sweep_desc* d, double* uN_
     if (rc != RT_OK) return rc;
   }
 
-  ProjAffine aff;
-  aff.mass = d->mass_values; aff.terms = d->term_values; aff.tril = d->tril_values; aff.row_of = row_of;
-  aff.nnz = nnz; aff.ld_u = N; aff.n_terms = Q; aff.dt = d->dt;
   for (long step = 0; step < nt; ++step) {
     const bool second = d->bdf2 && step > 0;
-    aff.bdf = second ? 1.5 : 1.0;
-    aff.coef = Q ? d->term_coef + step * B * Q : nullptr;
-    aff.uh = uh; aff.uh_prev = uhp; aff.extrapolate = d->bdf2 ? 1 : 0;
-    rc = rt_project_fused_ex(ctx, d->indptr, d->indices, d->mass_values, 1, 0, B, N, d->V, r, r, KN, &aff);
+    dim3 vgrid((unsigned)((nnz + 255) / 256), (unsigned)B);
+    hipLaunchKernelGGL(sweep_values_kernel, vgrid, dim3(256), 0, st, d->mass_values, d->term_values, Q,
+                       Q ? d->term_coef + step * B * Q : nullptr, d->tril_values, row_of, uh, uhp, d->bdf2 ? 1 : 0, nnz,
+                       N, second ? 1.5 : 1.0, d->dt, kval);
+    RT_HIP_CHECK(ctx, hipGetLastError());
+    rc = rt_project_fused(ctx, d->indptr, d->indices, kval, 1, nnz, B, N, d->V, r, r, KN);
     if (rc != RT_OK) return rc;
     const double c0 = d->bdf2 ? 2.0 : 1.0, c1 = d->bdf2 ? -0.5 : 0.0;  // u^{n-1} = 0 at step 0 reproduces BDF1
     // reference: step 0 of a BDF2 run uses M_N (2 u^0 - u^{-1}/2) with both zero (rom.py:451-458,921-924)
