@@ -19,7 +19,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int PK = 16;        // rows per stage
+constexpr int PK = 32;        // rows per stage
 constexpr int PT = 512;       // threads (8 waves)
 constexpr int RMAX = 128;
 
@@ -36,7 +36,7 @@ struct ProjParams {
   const int* win;      // [2 * stages]: column window (lo, hi) of every 16-row stage, hi = -1: not windowed
 };
 
-constexpr int WROWS = 32;     // V rows kept in LDS per stage (banded FE operators touch ~PK + 2*bandwidth)
+constexpr int WROWS = 48;     // V rows kept in LDS per stage (banded FE operators touch ~PK + 2*bandwidth)
 constexpr int EMAX = PT;      // entries of one stage staged through LDS (one per thread)
 constexpr int WREG = WROWS / 4;  // window doubles per thread in flight: column tid % 128, rows tid / 128 + 4 i
 
@@ -86,7 +86,9 @@ __global__ __launch_bounds__(PT, PACC <= 4 ? 4 : 2) void project_fused_kernel(co
     tj[q] = (t < ntile) ? 16 * (t % tr) : 0;
   }
   const int rp = tr * 16;                  // padded width
-  const int kk = tid >> 5, jg = tid & 31;  // B-operand mapping: 16 rows x 32 column groups
+  constexpr int CG = PT / PK;              // column groups of the B-operand mapping (PK rows x CG groups)
+  constexpr int NCOL = RMAX / CG;          // columns per thread: jg, jg + CG, ...
+  const int kk = tid / CG, jg = tid % CG;
 
   // registers of the stage in flight
   const int wrow = tid >> 7, wcol = tid & 127;
@@ -136,7 +138,9 @@ __global__ __launch_bounds__(PT, PACC <= 4 ? 4 : 2) void project_fused_kernel(co
     // B operand: rows of A_b V
     {
       const long k = k0 + kk;
-      double o0 = 0.0, o1 = 0.0, o2 = 0.0, o3 = 0.0;
+      double o[NCOL];
+#pragma unroll
+      for (int c = 0; c < NCOL; ++c) o[c] = 0.0;
       if (k < kend) {
         const long e0 = p.indptr[k], e1 = p.indptr[k + 1];
         if (windowed) {
@@ -145,27 +149,24 @@ __global__ __launch_bounds__(PT, PACC <= 4 ? 4 : 2) void project_fused_kernel(co
           for (int q = 0; q < cnt; ++q) {
             const double a = sVal[base + q];
             const double* vr = sW + sCol[base + q] * stride;
-            if (jg < rp) o0 = fma(a, vr[jg], o0);
-            if (jg + 32 < rp) o1 = fma(a, vr[jg + 32], o1);
-            if (jg + 64 < rp) o2 = fma(a, vr[jg + 64], o2);
-            if (jg + 96 < rp) o3 = fma(a, vr[jg + 96], o3);
+#pragma unroll
+            for (int c = 0; c < NCOL; ++c)
+              if (jg + CG * c < rp) o[c] = fma(a, vr[jg + CG * c], o[c]);
           }
         } else {
           for (long e = e0; e < e1; ++e) {
             const double a = dat[e * p.d_es];
             const double* vr = p.V + p.indices[e] * p.ldv;
-            if (jg < r) o0 = fma(a, vr[jg], o0);
-            if (jg + 32 < r) o1 = fma(a, vr[jg + 32], o1);
-            if (jg + 64 < r) o2 = fma(a, vr[jg + 64], o2);
-            if (jg + 96 < r) o3 = fma(a, vr[jg + 96], o3);
+#pragma unroll
+            for (int c = 0; c < NCOL; ++c)
+              if (jg + CG * c < r) o[c] = fma(a, vr[jg + CG * c], o[c]);
           }
         }
       }
       double* row = sB + kk * stride;
-      if (jg < rp) row[jg] = o0;
-      if (jg + 32 < rp) row[jg + 32] = o1;
-      if (jg + 64 < rp) row[jg + 64] = o2;
-      if (jg + 96 < rp) row[jg + 96] = o3;
+#pragma unroll
+      for (int c = 0; c < NCOL; ++c)
+        if (jg + CG * c < rp) row[jg + CG * c] = o[c];
     }
     __syncthreads();
     const double* cA = sW + abase * stride;
@@ -248,11 +249,11 @@ int rt_project_fused(rt_ctx* ctx, const int64_t* indptr, const int64_t* indices,
   static bool attr_set = false;
   if (!attr_set) {
     RT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&project_fused_kernel<2>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     RT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&project_fused_kernel<4>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     RT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&project_fused_kernel<8>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
     attr_set = true;
   }
   if (ctx->profile) {
