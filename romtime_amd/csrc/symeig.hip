@@ -21,7 +21,8 @@
 
 namespace {
 
-constexpr int TW = 16;      // workgroups of the tridiagonalisation
+constexpr int TW = 32;      // workgroups of the tridiagonalisation
+constexpr int LPR = 64;     // lanes per matrix row in the mat-vec / rank-2 update (TT / LPR rows per pass)
 constexpr int TT = 1024;    // threads per workgroup
 constexpr int NMAX = 512;
 
@@ -118,7 +119,7 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
     A[q] = (gi < n) ? p.G[(size_t)gi * n + j] : 0.0;
   }
   __syncthreads();
-  const int ty = tid >> 5, tx = tid & 31;  // 32 rows x 32 lanes
+  const int ty = tid / LPR, tx = tid % LPR;  // (TT / LPR) rows x LPR lanes
   int hop = 0;                              // counter target is hop * TW
 
   // step "-1": row 0 to everybody
@@ -150,14 +151,14 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
     double* Pk = p.P + (size_t)(k & 1) * n;
     double* Lk = p.P + (size_t)(2 + (k & 1)) * n;
     if (tau != 0.0) {
-      for (int li = ty; li < RB; li += 32) {
+      for (int li = ty; li < RB; li += TT / LPR) {
         const int gi = li * TW + wg;
         if (gi > k && gi < n) {
           const double* row = A + (size_t)li * n;
           double acc = 0.0;
-          for (int j = k + 1 + tx; j < n; j += 32) acc = fma(row[j], sv[j], acc);
+          for (int j = k + 1 + tx; j < n; j += LPR) acc = fma(row[j], sv[j], acc);
 #pragma unroll
-          for (int off = 16; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+          for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
           if (tx == 0) st_wt(&Pk[gi], tau * acc);
         }
       }
@@ -186,12 +187,12 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
     for (int j = k + 1 + tid; j < n; j += TT) sw[j] = fma(alpha2, sv[j], sp[j]);
     __syncthreads();
     // ---- A <- A - v w^T - w v^T on the local rows i > k, and on the look-ahead copy of row k+1 ----
-    for (int li = ty; li < RB; li += 32) {
+    for (int li = ty; li < RB; li += TT / LPR) {
       const int gi = li * TW + wg;
       if (gi > k && gi < n) {
         double* row = A + (size_t)li * n;
         const double vi = sv[gi], wi = sw[gi];
-        for (int j = k + 1 + tx; j < n; j += 32) row[j] -= vi * sw[j] + wi * sv[j];
+        for (int j = k + 1 + tx; j < n; j += LPR) row[j] -= vi * sw[j] + wi * sv[j];
       }
     }
     {

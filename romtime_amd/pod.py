@@ -34,6 +34,7 @@ from . import _lib, ops
 DROP_TOLERANCE = 1e-7  # pod.py:4 (the reference's docstring says 1e-8; the code is 1e-7)
 DEVICE_EIG = True      # small eigenproblem on the device (rt_sym_eig_*); False = host LAPACK
 DEVICE_EIG_MAX_N = 512
+RR_GAP = 1e-4           # smallest eigenvalue gap (relative to lam_1) for which inverse iteration is trusted as is
 TWO_PASS_RATIO = 1e-2  # one Gram pass: vectors good to ~eps (sigma_1/sigma_i)^2 <= 2e-12 above this ratio
 
 
@@ -216,18 +217,34 @@ def _pod_device_eig(X, G, colnorm, flag, normalize, num, tol, passes, want_vt, p
         VT = np.zeros((0, n)) if want_vt else None
     else:
         Z = ops.sym_eig_vectors(lam_d, r)                       # n x r
-        GZ = ops.gemm_nn(G, Z)
-        HS = torch.cat([ops.gemm_tn(Z, GZ), ops.gemm_tn(Z, Z)], dim=0).cpu().numpy()
-        H, S = 0.5 * (HS[:r] + HS[:r].T), 0.5 * (HS[r:] + HS[r:].T)
-        with _blas_threads(1):                                   # k x k: threads only burn the CPU quota
-            theta, C = small_eigh(H, S)                          # generalised Rayleigh-Ritz
-        theta, C = theta[::-1], C[:, ::-1]
-        if np.abs(theta - lam[:r]).max() > 1e-9 * max(lam[0], 1e-300):
-            raise _lib.RomtimeHipError("device eigenvectors failed the Rayleigh-Ritz cross-check")
-        T2 = ops.to_device(np.ascontiguousarray(C * _inv_or_zero(s[:r])), X.device)
+        # inverse iteration resolves an eigenvector to ~eps ||G|| / gap: with every gap among the kept
+        # eigenvalues (and to the first discarded one) above RR_GAP * lam_1 that is <= 2e-12 and the
+        # vectors are used as they are; closer eigenvalues get the k x k Rayleigh-Ritz step on G
+        gaps = lam[:r] - lam[1:r + 1] if r < n else np.r_[lam[:r - 1] - lam[1:r], lam[r - 1]]
+        if gaps.min() >= RR_GAP * max(lam[0], 1e-300):
+            C, C_is_identity = None, True
+        else:
+            GZ = ops.gemm_nn(G, Z)
+            HS = torch.cat([ops.gemm_tn(Z, GZ), ops.gemm_tn(Z, Z)], dim=0).cpu().numpy()
+            H, S = 0.5 * (HS[:r] + HS[:r].T), 0.5 * (HS[r:] + HS[r:].T)
+            with _blas_threads(1):                                   # k x k: threads only burn the CPU quota
+                theta, C = small_eigh(H, S)                          # generalised Rayleigh-Ritz
+            theta, C = theta[::-1], C[:, ::-1]
+            if np.abs(theta - lam[:r]).max() > 1e-9 * max(lam[0], 1e-300):
+                raise _lib.RomtimeHipError("device eigenvectors failed the Rayleigh-Ritz cross-check")
+            C_is_identity = False
+        scale = _inv_or_zero(s[:r])
+        T2 = ops.to_device(np.ascontiguousarray(np.diag(scale) if C_is_identity else C * scale), X.device)
         Zs = Z if not normalize else Z / colnorm[:, None]
-        Q = ops.gemm_nn(X, ops.gemm_nn(Zs.contiguous(), T2))
-        VT = np.ascontiguousarray((Z.cpu().numpy() @ C).T) if want_vt else None
+        if C_is_identity:
+            Q = ops.gemm_nn(X, (Zs * T2.diagonal()[None, :]).contiguous())
+        else:
+            Q = ops.gemm_nn(X, ops.gemm_nn(Zs.contiguous(), T2))
+        if want_vt:
+            Zh = Z.cpu().numpy()
+            VT = np.ascontiguousarray((Zh if C_is_identity else Zh @ C).T)
+        else:
+            VT = None
     if prof:
         torch.cuda.synchronize()
         t3 = time.perf_counter()
