@@ -23,11 +23,16 @@ using namespace rtk;
 
 namespace {
 
-template <int MT, int NT, bool KCA, bool KCB>
+// SKINNY: the 4 waves are stacked along M (each 16 MT rows x 16 NT columns) instead of 2 x 2, so an
+// output of 40 columns costs 3 MFMA tiles per row block, not the 4 of a 64-wide 2 x 2 tile; the B panel
+// is still loaded 64 wide (columns past Nn are zero-filled without touching memory).
+template <int MT, int NT, bool KCA, bool KCB, bool SKINNY = false>
 __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_mfma_kernel(const GemmParams p) {
-  constexpr int BM = 32 * MT, BN = 32 * NT;
+  constexpr int BM = SKINNY ? 64 * MT : 32 * MT;
+  constexpr int BN = SKINNY ? 16 * NT : 32 * NT;       // output columns covered by a tile
+  constexpr int BNP = SKINNY ? 64 : 32 * NT;            // width of the staged B panel
   using PA = Panel<BM, KCA>;
-  using PB = Panel<BN, KCB>;
+  using PB = Panel<BNP, KCB>;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* sA0 = smem;
   double* sA1 = smem + PA::LDS;
@@ -66,7 +71,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_mfma_kernel(const GemmPa
   const int nstages = (kend > kbeg) ? (int)((kend - kbeg + KB - 1) / KB) : 0;
 
   const int lane = tid & 63, wid = tid >> 6;
-  const int wm = wid >> 1, wn = wid & 1;
+  const int wm = SKINNY ? wid : (wid >> 1), wn = SKINNY ? 0 : (wid & 1);
   const int l15 = lane & 15, l4 = lane >> 4;
 
   d4 acc[MT][NT];
@@ -150,17 +155,17 @@ __global__ void gemm_reduce_kernel(const double* __restrict__ slab, long split_s
   C[i * c_rs + j * c_cs] = sum;
 }
 
-template <int MT, int NT, bool KCA, bool KCB>
+template <int MT, int NT, bool KCA, bool KCB, bool SKINNY = false>
 int launch(rt_ctx* ctx, const GemmParams& p, int grid) {
-  constexpr int BM = 32 * MT, BN = 32 * NT;
-  constexpr size_t lds = sizeof(double) * 2 * (Panel<BM, KCA>::LDS + Panel<BN, KCB>::LDS);
+  constexpr int BM = SKINNY ? 64 * MT : 32 * MT, BNP = SKINNY ? 64 : 32 * NT;
+  constexpr size_t lds = sizeof(double) * 2 * (Panel<BM, KCA>::LDS + Panel<BNP, KCB>::LDS);
   static bool attr_set = false;
   if (!attr_set) {
-    RT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_mfma_kernel<MT, NT, KCA, KCB>),
+    RT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_mfma_kernel<MT, NT, KCA, KCB, SKINNY>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_f64_mfma_kernel<MT, NT, KCA, KCB>), dim3(grid), dim3(NTHREADS), lds, ctx->stream, p);
+  hipLaunchKernelGGL((gemm_f64_mfma_kernel<MT, NT, KCA, KCB, SKINNY>), dim3(grid), dim3(NTHREADS), lds, ctx->stream, p);
   RT_HIP_CHECK(ctx, hipGetLastError());
   return RT_OK;
 }
@@ -183,6 +188,14 @@ int launch_nt(rt_ctx* ctx, const GemmParams& p, int grid, int nt, bool kca, bool
   }
 }
 
+template <int NT>
+int launch_skinny(rt_ctx* ctx, const GemmParams& p, int grid, bool kca, bool kcb) {
+  if (kca && kcb) return launch<2, NT, true, true, true>(ctx, p, grid);
+  if (kca && !kcb) return launch<2, NT, true, false, true>(ctx, p, grid);
+  if (!kca && kcb) return launch<2, NT, false, true, true>(ctx, p, grid);
+  return launch<2, NT, false, false, true>(ctx, p, grid);
+}
+
 int tile_units(long extent) {  // tile extent in units of 32 (1..4)
   if (extent >= 128) return 4;
   return (int)((extent + 31) / 32);
@@ -203,7 +216,10 @@ int rt_gemm_strided(rt_ctx* ctx, const double* A, int64_t a_ks, int64_t a_ms, co
   const bool kcb = (b_ks == 1) && !(b_ns == 1 && Nn > 1);
   int mt = tile_units(M), nt = tile_units(Nn);
   if (symmetric) nt = mt;
-  const int BM = 32 * mt, BN = 32 * nt;
+  // tall output with <= 64 columns (POD back-projection, lift of a batch of reduced vectors)
+  const bool skinny = !symmetric && Nn <= 64 && M >= 256;
+  const int snt = (int)((Nn + 15) / 16);
+  const int BM = skinny ? 128 : 32 * mt, BN = skinny ? 16 * snt : 32 * nt;
 
   GemmParams p;
   p.A = A; p.a_ks = a_ks; p.a_ms = a_ms;
@@ -253,7 +269,7 @@ int rt_gemm_strided(rt_ctx* ctx, const double* A, int64_t a_ks, int64_t a_ms, co
   const int grid = (splits == 1) ? p.ntiles : 8 * ((splits + 7) / 8) * p.ntiles;
   ctx->last_grid = grid; ctx->last_splits = splits; ctx->last_tile = BM * 1000 + BN;
 
-  int rc;
+  int rc = RT_OK;
   if (ctx->profile) {
     if (!ctx->ev0) {
       RT_HIP_CHECK(ctx, hipEventCreate(&ctx->ev0));
@@ -261,6 +277,14 @@ int rt_gemm_strided(rt_ctx* ctx, const double* A, int64_t a_ks, int64_t a_ms, co
     }
     RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   }
+  if (skinny) {
+    switch (snt) {
+      case 1: rc = launch_skinny<1>(ctx, p, grid, kca, kcb); break;
+      case 2: rc = launch_skinny<2>(ctx, p, grid, kca, kcb); break;
+      case 3: rc = launch_skinny<3>(ctx, p, grid, kca, kcb); break;
+      default: rc = launch_skinny<4>(ctx, p, grid, kca, kcb); break;
+    }
+  } else
   switch (mt) {
     case 1: rc = launch_nt<1>(ctx, p, grid, nt, kca, kcb); break;
     case 2: rc = launch_nt<2>(ctx, p, grid, nt, kca, kcb); break;
