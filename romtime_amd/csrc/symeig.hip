@@ -76,54 +76,34 @@ __device__ __forceinline__ double block_sum(double x, double* s_red) {
   return t;
 }
 
-// Householder vector of x = row[k+1 .. n-1] (dlarfg): writes v (v[k+1] = 1) into sv, returns tau, beta.
-// Called by ALL workgroups on identical data, so every workgroup derives bit-identical (v, tau).
-__device__ __forceinline__ void make_reflector(const double* row, int k, int n, double* sv, double* s_red,
-                                               double* tau_out, double* beta_out) {
-  const int tid = threadIdx.x;
-  double part = 0.0;
-  for (int j = k + 2 + tid; j < n; j += TT) part += row[j] * row[j];
-  const double xnorm2 = block_sum(part, s_red);
-  const double alpha = row[k + 1];
-  double tau, beta, scale;
-  if (xnorm2 == 0.0) {
-    tau = 0.0; beta = alpha; scale = 0.0;
-  } else {
-    beta = -copysign(sqrt(alpha * alpha + xnorm2), alpha);
-    tau = (beta - alpha) / beta;
-    scale = 1.0 / (alpha - beta);
-  }
-  for (int j = k + 1 + tid; j < n; j += TT) sv[j] = (j == k + 1) ? 1.0 : row[j] * scale;
-  __syncthreads();
-  *tau_out = tau;
-  *beta_out = beta;
-}
-
 // One inter-workgroup hand-off per column: together with its slice of p = tau A v, the owner of row
 // k+1 publishes that row as it stands BEFORE the rank-2 update of step k; after the hand-off every
-// workgroup applies the update to its copy and derives the next reflector redundantly.
+// workgroup applies the update to its copy and derives the next reflector redundantly (and, the
+// arithmetic being identical, bit-identically).  All O(n) vector work of a step (reflector, p.v, w, the
+// look-ahead row) is done by wave 0 alone in registers with shuffle reductions - 8 elements per lane -
+// so a step costs four workgroup barriers; the other 15 waves only do the O(n^2/P) mat-vec and update.
 __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int n = p.n, tid = threadIdx.x, wg = blockIdx.x;
+  const int n = p.n, tid = threadIdx.x, wg = blockIdx.x, lane = tid & 63, wid = tid >> 6;
   const int RB = (n + TW - 1) / TW;
   double* A = sm;                 // RB x n, local row li <-> global row li*TW + wg
-  double* sv = sm + (size_t)RB * n;
-  double* sw = sv + n;
-  double* sp = sw + n;
-  double* sl = sp + n;            // look-ahead row
-  double* s_red = sl + n;         // 16 doubles
+  double* svb = sm + (size_t)RB * n;  // v, double buffered by step parity (2 x n)
+  double* sw = svb + 2 * n;
+  double* sl = sw + n;            // current row k (entries j >= k), maintained by wave 0
   __shared__ int s_abort;
+  __shared__ double s_tau;
+  constexpr int PER = NMAX / 64;
 
   for (int q = tid; q < RB * n; q += TT) {
     const int li = q / n, j = q % n, gi = li * TW + wg;
     A[q] = (gi < n) ? p.G[(size_t)gi * n + j] : 0.0;
   }
   __syncthreads();
-  const int ty = tid / LPR, tx = tid % LPR;  // (TT / LPR) rows x LPR lanes
-  int hop = 0;                              // counter target is hop * TW
+  const int ty = tid / LPR, tx = tid % LPR;  // (TT / LPR) rows x LPR lanes; with LPR = 64: ty == wave id
+  int hop = 0;                                // counter target is hop * TW
 
   // step "-1": row 0 to everybody
-  double* L0 = p.P + (size_t)2 * n;         // P = [p even | p odd | row even | row odd]
+  double* L0 = p.P + (size_t)2 * n;           // P = [p even | p odd | row even | row odd]
   if (wg == 0)
     for (int j = tid; j < n; j += TT) st_wt(&L0[j], A[j]);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -134,59 +114,113 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
   for (int j = tid; j < n; j += TT) sl[j] = ld_wt(&L0[j]);
   __syncthreads();
 
+  double v[PER];  // wave 0: the reflector of the current step, element j = k + 1 + lane + 64 q
   for (int k = 0; k + 2 < n; ++k) {
-    // sl holds the current row k (entries j >= k): reflector of step k, identical in every workgroup
-    double tau, beta;
-    make_reflector(sl, k, n, sv, s_red, &tau, &beta);
-    if (wg == k % TW) {
-      double* vk = p.V + (size_t)k * n;
-      for (int j = k + 1 + tid; j < n; j += TT) vk[j] = sv[j];
-      if (tid == 0) {
-        p.tau[k] = tau;
-        p.d[k] = sl[k];
-        p.e[k] = beta;
+    double* sv = svb + (size_t)(k & 1) * n;
+    if (wid == 0) {
+      // reflector of row k (dlarfg): identical data and arithmetic in every workgroup
+      double part = 0.0;
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int j = k + 1 + lane + 64 * q;
+        v[q] = (j < n) ? sl[j] : 0.0;
+        if (!(lane == 0 && q == 0)) part = fma(v[q], v[q], part);
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+      const double alpha = __shfl(v[0], 0);
+      double tau, beta, scale;
+      if (part == 0.0) {
+        tau = 0.0; beta = alpha; scale = 0.0;
+      } else {
+        beta = -copysign(sqrt(alpha * alpha + part), alpha);
+        tau = (beta - alpha) / beta;
+        scale = 1.0 / (alpha - beta);
+      }
+      const bool owner = (wg == k % TW);
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int j = k + 1 + lane + 64 * q;
+        v[q] = (lane == 0 && q == 0) ? 1.0 : v[q] * scale;
+        if (j < n) {
+          sv[j] = v[q];
+          if (owner) p.V[(size_t)k * n + j] = v[q];
+        }
+      }
+      if (lane == 0) {
+        s_tau = tau;
+        if (owner) {
+          p.tau[k] = tau;
+          p.d[k] = sl[k];
+          p.e[k] = beta;
+        }
       }
     }
-    // ---- p = tau * A v on the local rows i > k; the owner of row k+1 adds that row (pre-update) ----
+    __syncthreads();  // B1: sv, s_tau
+    const double tau = s_tau;
+    // ---- p = tau * A v on the local rows i > k; the wave that holds row k+1 adds that row (pre-update) ----
     double* Pk = p.P + (size_t)(k & 1) * n;
     double* Lk = p.P + (size_t)(2 + (k & 1)) * n;
-    if (tau != 0.0) {
-      for (int li = ty; li < RB; li += TT / LPR) {
-        const int gi = li * TW + wg;
-        if (gi > k && gi < n) {
-          const double* row = A + (size_t)li * n;
+    for (int li = ty; li < RB; li += TT / LPR) {
+      const int gi = li * TW + wg;
+      if (gi > k && gi < n) {
+        const double* row = A + (size_t)li * n;
+        if (tau != 0.0) {
           double acc = 0.0;
           for (int j = k + 1 + tx; j < n; j += LPR) acc = fma(row[j], sv[j], acc);
 #pragma unroll
           for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
           if (tx == 0) st_wt(&Pk[gi], tau * acc);
         }
+        if (gi == k + 1)
+          for (int j = k + 1 + tx; j < n; j += LPR) st_wt(&Lk[j], row[j]);
       }
     }
-    if (wg == (k + 1) % TW) {
-      const double* row = A + (size_t)((k + 1) / TW) * n;
-      for (int j = k + 1 + tid; j < n; j += TT) st_wt(&Lk[j], row[j]);
-    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    // one monotonic counter: nobody can arrive for hop h+1 before all 16 arrived for hop h, and the
-    // payload buffers alternate, so a fast workgroup never overwrites what a slow one still reads
+    __syncthreads();  // B2
+    // one monotonic counter: nobody can arrive for hop h+1 before all arrived for hop h, and the payload
+    // buffers alternate, so a fast workgroup never overwrites what a slow one still reads
     if (tid == 0) __hip_atomic_fetch_add(&p.flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     ++hop;
-    // ---- the hand-off ---------------------------------------------------------------------------
-    if (!wait_flag(&p.flags[1], hop * TW, &p.flags[3], &s_abort)) return;
-    for (int j = k + 1 + tid; j < n; j += TT) {
-      sl[j] = ld_wt(&Lk[j]);
-      if (tau != 0.0) sp[j] = ld_wt(&Pk[j]);
+    if (!wait_flag(&p.flags[1], hop * TW, &p.flags[3], &s_abort)) return;  // B3 inside
+    if (wid == 0) {
+      // wave 0 takes p and the next row straight into registers
+      double pv[PER], lv[PER];
+#pragma unroll
+      for (int q = 0; q < PER; ++q) {
+        const int j = k + 1 + lane + 64 * q;
+        lv[q] = (j < n) ? ld_wt(&Lk[j]) : 0.0;
+        pv[q] = (j < n && tau != 0.0) ? ld_wt(&Pk[j]) : 0.0;
+      }
+      if (tau != 0.0) {
+        double dot = 0.0;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) dot = fma(pv[q], v[q], dot);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+        const double alpha2 = -0.5 * tau * dot;
+#pragma unroll
+        for (int q = 0; q < PER; ++q) pv[q] = fma(alpha2, v[q], pv[q]);  // pv now holds w
+        const double w1 = __shfl(pv[0], 0);                              // w_{k+1}; v_{k+1} = 1
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+          const int j = k + 1 + lane + 64 * q;
+          if (j < n) {
+            sw[j] = pv[q];
+            sl[j] = lv[q] - (pv[q] + w1 * v[q]);  // row k+1 after the rank-2 update
+          }
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < PER; ++q) {
+          const int j = k + 1 + lane + 64 * q;
+          if (j < n) sl[j] = lv[q];
+        }
+      }
     }
-    __syncthreads();
-    if (tau == 0.0) continue;  // H = I: nothing to update, sl already is the next row
-    double part = 0.0;
-    for (int j = k + 1 + tid; j < n; j += TT) part += sp[j] * sv[j];
-    const double alpha2 = -0.5 * tau * block_sum(part, s_red);
-    for (int j = k + 1 + tid; j < n; j += TT) sw[j] = fma(alpha2, sv[j], sp[j]);
-    __syncthreads();
-    // ---- A <- A - v w^T - w v^T on the local rows i > k, and on the look-ahead copy of row k+1 ----
+    __syncthreads();  // B5: sw, sl
+    if (tau == 0.0) continue;
+    // ---- A <- A - v w^T - w v^T on the local rows i > k (each wave touches only the rows it also reads) ----
     for (int li = ty; li < RB; li += TT / LPR) {
       const int gi = li * TW + wg;
       if (gi > k && gi < n) {
@@ -195,12 +229,8 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
         for (int j = k + 1 + tx; j < n; j += LPR) row[j] -= vi * sw[j] + wi * sv[j];
       }
     }
-    {
-      const double vi = sv[k + 1], wi = sw[k + 1];
-      for (int j = k + 1 + tid; j < n; j += TT) sl[j] -= vi * sw[j] + wi * sv[j];
-    }
-    __syncthreads();
   }
+  __syncthreads();
   // trailing 2 x 2: sl holds row n-2 (entries n-2, n-1); row n-1 is with its owner
   if (wg == (n - 2) % TW && tid == 0) {
     p.d[n - 2] = sl[n - 2];
@@ -212,7 +242,6 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
   }
 }
 
-// number of eigenvalues of T smaller than x (Sturm count, dstebz recurrence)
 // 1/q by v_rcp_f64 and one Newton step (<= 1 ulp): the IEEE divide sequence is ~4x as long and the
 // count only has to be that of a matrix within eps of T
 __device__ __forceinline__ double fast_rcp(double q) {
@@ -468,7 +497,7 @@ extern "C" int rt_sym_eig_values(rt_ctx* ctx, const double* G, int64_t n, double
   hipLaunchKernelGGL(symeig_init_kernel, dim3(1), dim3(256), 0, st, tp.flags, tp.tau, (int)n);
 
   const int RB = (int)((n + TW - 1) / TW);
-  const size_t lds = sizeof(double) * ((size_t)RB * n + 4 * n + 16);
+  const size_t lds = sizeof(double) * ((size_t)RB * n + 4 * n + 16);  // A slab | v (x2) | w | row
   static bool attr_set = false;
   if (!attr_set) {
     RT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&symeig_tridiag_kernel),
