@@ -261,61 +261,74 @@ __device__ __forceinline__ int sturm_count(const double* d, const double* e2, in
   return c;
 }
 
-// lam[j] = j-th LARGEST eigenvalue of T; one wave per eigenvalue
 __global__ void symeig_init_kernel(int* flags, double* tau, int n) {
   for (int i = threadIdx.x; i < 8; i += blockDim.x) flags[i] = 0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) tau[i] = 0.0;
 }
 
-__global__ __launch_bounds__(TT) void symeig_bisect_kernel(const double* __restrict__ d, const double* __restrict__ e,
+// lam[j] = j-th LARGEST eigenvalue of T.  One single-wave workgroup per eigenvalue, so the n waves spread
+// over all CUs (about one wave per two SIMDs: latency-bound), and each lane runs NS independent Sturm
+// recurrences to fill the rcp/fma latency: 64 NS + 1 sections per pass, 7 passes (257^7 > 2^53).
+__global__ __launch_bounds__(64) void symeig_bisect_kernel(const double* __restrict__ d, const double* __restrict__ e,
                                                            int n, double* __restrict__ lam, const int* flags,
                                                            int* status) {
   if (status && blockIdx.x == 0 && threadIdx.x == 0) *status = flags[3];
   __shared__ double sd[NMAX], se2[NMAX];
-  __shared__ double s_red[4];
-  const int tid = threadIdx.x, lane = tid & 63;
-  for (int i = tid; i < n; i += TT) {
-    sd[i] = d[i];
-    se2[i] = (i + 1 < n) ? e[i] * e[i] : 0.0;
+  const int lane = threadIdx.x;
+  double glo = 1e300, ghi = -1e300, emax = 0.0;
+  for (int i = lane; i < n; i += 64) {
+    const double di = d[i], ei = (i + 1 < n) ? e[i] : 0.0, el = (i > 0) ? fabs(e[i - 1]) : 0.0;
+    sd[i] = di;
+    se2[i] = ei * ei;
+    glo = fmin(glo, di - el - fabs(ei));
+    ghi = fmax(ghi, di + el + fabs(ei));
+    emax = fmax(emax, ei * ei);
   }
-  __syncthreads();
-  // Gershgorin interval and pivmin, redundantly per wave (wave 0 publishes)
-  if (tid < 64) {
-    double lo = 1e300, hi = -1e300, emax = 0.0;
-    for (int i = lane; i < n; i += 64) {
-      const double el = (i > 0) ? fabs(e[i - 1]) : 0.0, er = (i + 1 < n) ? fabs(e[i]) : 0.0;
-      lo = fmin(lo, sd[i] - el - er);
-      hi = fmax(hi, sd[i] + el + er);
-      emax = fmax(emax, se2[i]);
-    }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      lo = fmin(lo, __shfl_xor(lo, off));
-      hi = fmax(hi, __shfl_xor(hi, off));
-      emax = fmax(emax, __shfl_xor(emax, off));
-    }
-    if (lane == 0) {
-      const double tn = fmax(fabs(lo), fabs(hi));
-      s_red[0] = lo - 2.2e-16 * tn * n - 1e-300;
-      s_red[1] = hi + 2.2e-16 * tn * n + 1e-300;
-      s_red[2] = 2.2250738585072014e-308 * fmax(1.0, emax);
-    }
+  for (int off = 32; off > 0; off >>= 1) {
+    glo = fmin(glo, __shfl_xor(glo, off));
+    ghi = fmax(ghi, __shfl_xor(ghi, off));
+    emax = fmax(emax, __shfl_xor(emax, off));
   }
   __syncthreads();
-  const int j = blockIdx.x * (TT / 64) + (tid >> 6);  // descending index
-  if (j >= n) return;
-  const int want = n - j;  // ascending rank (1-based): smallest x with count(x) >= want
-  double lo = s_red[0], hi = s_red[1];
-  const double pivmin = s_red[2];
-  for (int pass = 0; pass < 10; ++pass) {
-    const double h = (hi - lo) / 65.0;
-    const double x = lo + h * (lane + 1);
-    const int c = sturm_count(sd, se2, n, x, pivmin);
-    const unsigned long long ge = __ballot(c >= want);
-    if (ge == 0ull) {
-      lo = lo + h * 64;
+  const double tn = fmax(fabs(glo), fabs(ghi));
+  double lo = glo - 2.2e-16 * tn * n - 1e-300, hi = ghi + 2.2e-16 * tn * n + 1e-300;
+  const double pivmin = 2.2250738585072014e-308 * fmax(1.0, emax);
+  const int j = blockIdx.x;      // descending index
+  const int want = n - j;        // ascending rank (1-based): smallest x with count(x) >= want
+  constexpr int NS = 4;
+  constexpr int NSEC = 64 * NS + 1;
+  for (int pass = 0; pass < 7; ++pass) {
+    const double h = (hi - lo) / NSEC;
+    const double x0 = lo + h * (NS * lane + 1), x1 = x0 + h, x2 = x0 + 2 * h, x3 = x0 + 3 * h;
+    double q0 = sd[0] - x0, q1 = sd[0] - x1, q2 = sd[0] - x2, q3 = sd[0] - x3;
+    if (fabs(q0) < pivmin) q0 = -pivmin;
+    if (fabs(q1) < pivmin) q1 = -pivmin;
+    if (fabs(q2) < pivmin) q2 = -pivmin;
+    if (fabs(q3) < pivmin) q3 = -pivmin;
+    int c0 = (q0 < 0.0), c1 = (q1 < 0.0), c2 = (q2 < 0.0), c3 = (q3 < 0.0);
+    for (int i = 1; i < n; ++i) {
+      const double di = sd[i], ei = se2[i - 1];
+      q0 = fma(-ei, fast_rcp(q0), di - x0);
+      q1 = fma(-ei, fast_rcp(q1), di - x1);
+      q2 = fma(-ei, fast_rcp(q2), di - x2);
+      q3 = fma(-ei, fast_rcp(q3), di - x3);
+      if (fabs(q0) < pivmin) q0 = -pivmin;
+      if (fabs(q1) < pivmin) q1 = -pivmin;
+      if (fabs(q2) < pivmin) q2 = -pivmin;
+      if (fabs(q3) < pivmin) q3 = -pivmin;
+      c0 += (q0 < 0.0); c1 += (q1 < 0.0); c2 += (q2 < 0.0); c3 += (q3 < 0.0);
+    }
+    int first = 64 * NS;  // index of the first shift whose count reaches `want` (none: 64 NS)
+    if (c3 >= want) first = NS * lane + 3;
+    if (c2 >= want) first = NS * lane + 2;
+    if (c1 >= want) first = NS * lane + 1;
+    if (c0 >= want) first = NS * lane;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) first = min(first, __shfl_xor(first, off));
+    if (first == 64 * NS) {
+      lo = lo + h * (64 * NS);
     } else {
-      const int first = __ffsll((long long)ge) - 1;
       hi = lo + h * (first + 1);
       lo = lo + h * first;
     }
@@ -506,7 +519,7 @@ extern "C" int rt_sym_eig_values(rt_ctx* ctx, const double* G, int64_t n, double
   }
   hipLaunchKernelGGL(symeig_tridiag_kernel, dim3(TW), dim3(TT), lds, st, tp);
   RT_HIP_CHECK(ctx, hipGetLastError());
-  hipLaunchKernelGGL(symeig_bisect_kernel, dim3((unsigned)((n + 15) / 16)), dim3(TT), 0, st, tp.d, tp.e, (int)n, lam,
+  hipLaunchKernelGGL(symeig_bisect_kernel, dim3((unsigned)n), dim3(64), 0, st, tp.d, tp.e, (int)n, lam,
                      tp.flags, status);
   RT_HIP_CHECK(ctx, hipGetLastError());
   g_state.tp = tp; g_state.n = n; g_state.base = base;
