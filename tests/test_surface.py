@@ -356,3 +356,41 @@ def test_rom_offline_hip():
 @pytest.mark.gpu
 def test_to_rom_hip():
     check_to_rom_roundtrip()
+
+
+def check_orth_odd_shapes():
+    """Shapes and inputs at the edges of the device path (n < 3 uses the host eigensolver, F-ordered views,
+    CUDA tensors in -> CUDA tensor out, all-zero snapshots), each against the oracle."""
+    import torch
+
+    from romtime_amd import orth
+
+    rng = np.random.RandomState(11)
+    for N, n, kw in [(5, 2, {}), (50, 1, {}), (1000, 3, dict(num=2)), (37, 5, dict(tol=0.99)), (300, 17, dict(num=40)),
+                     (2000, 64, dict(num=10)), (9000, 130, dict(num=12, normalize=False))]:
+        X = rng.standard_normal((N, n)) * 10.0 ** (-0.3 * np.arange(n))
+        for arr in (np.ascontiguousarray(X), np.asfortranarray(X)):
+            Q, s, e = orth(arr, **kw)
+            Qr, sr, er = oracle.orth(X.copy(), **kw)
+            assert Q.shape == Qr.shape and s.shape == sr.shape
+            assert np.all(np.abs(s - sr) <= 2e-13 * sr[0] + 8 * EPS * sr[0] ** 2 / np.maximum(sr, 1e-300))
+            if Q.shape[1]:
+                assert np.linalg.norm(Q @ (Q.T @ Qr) - Qr, 2) < 1e-9
+    # all-zero snapshots: energy is 0/0 = NaN in the reference as well; nothing is kept
+    Z = np.zeros((20, 4))
+    Q, s, e = orth(Z, normalize=False)
+    Qr, sr, er = oracle.orth(Z, normalize=False)
+    assert Q.shape == Qr.shape == (20, 0) and np.all(s == 0) and np.all(np.isnan(e)) and np.all(np.isnan(er))
+    if torch.cuda.is_available():
+        Xd = torch.from_numpy(rng.standard_normal((500, 8))).cuda()
+        Qd, s, e = orth(Xd, num=3)
+        assert isinstance(Qd, torch.Tensor) and Qd.is_cuda and Qd.shape == (500, 3)
+
+
+def test_orth_odd_shapes_hostlogic(cpu_ops):
+    check_orth_odd_shapes()
+
+
+@pytest.mark.gpu
+def test_orth_odd_shapes_hip():
+    check_orth_odd_shapes()
