@@ -14,16 +14,11 @@ from .utils import compute_error
 
 
 class Reductor:
-    FOM = ProblemType.FOM
-    ROM = ProblemType.ROM
+    """Base of every reduction object.  ``FOM`` / ``ROM`` select the coordinates an interpolant is
+    returned in; the ``BASIS_*`` / ``SPECTRUM_*`` / ``ENERGY_*`` attributes are the report keys of
+    the tree walk (same strings as ``romtime.conventions.Treewalk``)."""
 
-    BASIS_AFTER_WALK = Treewalk.BASIS_AFTER_WALK
-    BASIS_FINAL = Treewalk.BASIS_FINAL
-    BASIS_TIME = Treewalk.BASIS_TIME
-    ENERGY_MU = Treewalk.ENERGY_MU
-    ENERGY_TIME = Treewalk.ENERGY_TIME
-    SPECTRUM_MU = Treewalk.SPECTRUM_MU
-    SPECTRUM_TIME = Treewalk.SPECTRUM_TIME
+    FOM, ROM = ProblemType.FOM, ProblemType.ROM
 
     def __init__(self, grid=None) -> None:
         self.grid = grid
@@ -72,3 +67,7 @@ class Reductor:
             for idx, err in self.errors_rom.items()
         }
         self.summary_errors = pd.DataFrame(rows).T
+
+
+for _key in Treewalk.keys():  # Reductor.BASIS_FINAL, Reductor.SPECTRUM_TIME, ...
+    setattr(Reductor, _key, getattr(Treewalk, _key))
