@@ -8,19 +8,18 @@ Algorithm (device work through the C ABI, see include/romtime_hip.h):
   pass 1   G = X^T X                        rt_gram        (FP64 MFMA; the only O(N n^2) step)
            [row-sharded X: all-reduce G over RCCL/xGMI here]
            colnorm = sqrt(diag G), G <- D^-1 G D^-1        rt_gram_scale  (normalize=True, pod.py:31-33)
-           G = W L W^T                      small n x n symmetric eigenproblem (host LAPACK)
+           G = W L W^T                      rt_sym_eig_values / _vectors (device; host LAPACK for n > 512)
            sigma = sqrt(L), energy, truncation -> r
            Q = X (D^-1 W_r S_r^-1)          rt_gemm_nn     (back-projection)
 
-  pass 2   (only when a kept mode has sigma_r/sigma_1 < TWO_PASS_RATIO, or passes=2)
-           Y = X (D^-1 W)   full rotation   rt_gemm_nn
-           G2 = Y^T Y                       rt_gram  [+ all-reduce]
-           G2 = W2 L2 W2^T                  rt_host_jacobi_eigh (relative accuracy on the graded G2)
-           Q = Y (W2_r S_r^-1)              rt_gemm_nn
+  deep spectra (a kept mode with sigma_r/sigma_1 < TWO_PASS_RATIO): deflated levels (_pod_deflated) --
+           accept the modes within 1e-2 of the current largest, X <- X - Q (Q^T X) (rt_gemm_tn/_nn),
+           Gram + eigensolve again; every level runs on the device.
+  passes=2 keeps the alternative rotation + host Jacobi route (rt_host_jacobi_eigh).
 
-One pass reproduces dgesvd's left singular vectors to ~eps (sigma_1/sigma_i)^2; the second
-pass brings that to ~eps sigma_1/sigma_i, which is dgesvd's own accuracy (measured against a
-long-double Jacobi SVD; DESIGN.md "POD accuracy").
+One pass reproduces dgesvd's left singular vectors to ~eps (sigma_1/sigma_i)^2; both deep routes bring
+that to ~eps sigma_1/sigma_i, dgesvd's own accuracy (measured against a long-double Jacobi SVD;
+DESIGN.md "POD accuracy").
 """
 from __future__ import annotations
 
@@ -86,7 +85,7 @@ def _eigh_desc(G: np.ndarray):
     descending (used by the two-pass route, which needs the full rotation)."""
     with _blas_threads(8):
         lam, W = np.linalg.eigh(G)
-    return lam[::-1].copy(), np.ascontiguousarray(W[:, ::-1])
+    return lam[::-1].copy(), W[:, ::-1].copy(order="C")
 
 
 def jacobi_eigh(G: np.ndarray, max_sweeps: int = 40):
@@ -115,144 +114,182 @@ def _inv_or_zero(s):
     return out
 
 
+class _SmallEig:
+    """Eigen-decomposition of the n x n Gram matrix: all eigenvalues (host array, descending) at once,
+    leading eigenvectors on request (device, n x k).  3 <= n <= 512 runs on the device
+    (rt_sym_eig_values / rt_sym_eig_vectors, Rayleigh-Ritz polish on G when kept eigenvalues are
+    closer than RR_GAP * lam_1); other sizes use host LAPACK."""
+
+    def __init__(self, G: torch.Tensor, extra=()):
+        self.G, self.n = G, G.shape[0]
+        self.on_device = bool(G.is_cuda and DEVICE_EIG and 3 <= self.n <= DEVICE_EIG_MAX_N)
+        if self.on_device:
+            self.lam_d, status = ops.sym_eig_values(G)
+            head = torch.cat([self.lam_d, status.to(torch.float64)] + [e.to(torch.float64).reshape(-1) for e in extra])
+            head = head.cpu().numpy()  # the one device->host transfer of the step
+            self.lam, self.extra = head[: self.n], head[self.n + 1:]
+            if int(head[self.n]) != 0:
+                raise _lib.RomtimeHipError("rt_sym_eig_values: inter-workgroup hand-off timed out")
+        else:
+            Gh = G.cpu().numpy()
+            self.extra = np.concatenate([np.atleast_1d(e.cpu().numpy()).astype(float) for e in extra]) if extra else np.zeros(0)
+            self.lam, self.W = _eigh_desc(Gh)
+
+    def vectors(self, k: int) -> torch.Tensor:
+        """n x k eigenvectors of the k largest eigenvalues (must be called before any other device
+        operator that uses the ctx workspace, see rt_sym_eig_vectors)."""
+        from scipy.linalg import eigh as small_eigh
+
+        n, lam = self.n, self.lam
+        if not self.on_device:
+            return ops.to_device(np.ascontiguousarray(self.W[:, :k]), self.G.device)
+        Z = ops.sym_eig_vectors(self.lam_d, k)
+        # inverse iteration resolves an eigenvector to ~eps ||G|| / gap: with every gap among the kept
+        # eigenvalues (and to the first discarded one) above RR_GAP * lam_1 that is <= 2e-12 and the
+        # vectors are used as they are; closer eigenvalues get a k x k Rayleigh-Ritz step on G
+        gaps = lam[:k] - lam[1:k + 1] if k < n else np.r_[lam[:k - 1] - lam[1:k], lam[k - 1]]
+        if gaps.min() >= RR_GAP * max(lam[0], 1e-300):
+            return Z
+        GZ = ops.gemm_nn(self.G, Z)
+        HS = torch.cat([ops.gemm_tn(Z, GZ), ops.gemm_tn(Z, Z)], dim=0).cpu().numpy()
+        H, S = 0.5 * (HS[:k] + HS[:k].T), 0.5 * (HS[k:] + HS[k:].T)
+        with _blas_threads(1):  # k x k: threads only burn the CPU quota
+            theta, C = small_eigh(H, S)
+        theta, C = theta[::-1], np.ascontiguousarray(C[:, ::-1])
+        if np.abs(theta - lam[:k]).max() > 1e-9 * max(lam[0], 1e-300):
+            raise _lib.RomtimeHipError("device eigenvectors failed the Rayleigh-Ritz cross-check")
+        return ops.gemm_nn(Z, ops.to_device(C, Z.device))
+
+
+def _allreduce(G, group):
+    if group is not None:
+        import torch.distributed as dist
+
+        dist.all_reduce(G, op=dist.ReduceOp.SUM, group=group)
+    return G
+
+
 def pod_device(X: torch.Tensor, num=None, tol=None, normalize=True, passes=None, group=None, want_vt=False):
     """POD of a device-resident snapshot matrix (N_local x n).  Returns a dict with
     ``Q`` (device, N_local x r, row-major), ``s``, ``energy`` (host, all n), ``VT`` (host r x n
     or None), ``r``, ``passes``.  With ``group`` (a torch.distributed process group) X is this
-    rank's row slab and the Gram matrices are summed over the group."""
+    rank's row slab and the Gram matrices are summed over the group.
+
+    ``passes``: None = automatic (one Gram pass when every kept mode has sigma_r/sigma_1 >=
+    TWO_PASS_RATIO, otherwise deflated levels), 1 = one pass, 2 = rotation + host Jacobi,
+    "deflate" = deflated levels."""
+    import time
+
     if X.dim() != 2:
         raise ValueError("snapshots must be a 2-D array")
     n = X.shape[1]
-
-    def allreduce(G):
-        if group is not None:
-            import torch.distributed as dist
-
-            dist.all_reduce(G, op=dist.ReduceOp.SUM, group=group)
-        return G
-
-    import time
-
     ctx = _lib.Context.current() if X.is_cuda else None
-    prof = bool(ctx is not None and ctx.lib is not None and _profiling(ctx))
+    prof = bool(ctx is not None and _profiling(ctx))
     t0 = time.perf_counter()
     G = ops.gram(X)
     if prof:
         LAST_TIMINGS.clear()
         LAST_TIMINGS["gram_kernel_ms"] = ctx.last_gemm_ms()
         LAST_TIMINGS["gram_ms"] = 1e3 * (time.perf_counter() - t0)
-    G = allreduce(G)
+    G = _allreduce(G, group)
     colnorm, flag = ops.gram_scale(G, normalize)
-    dev_eig = X.is_cuda and passes != 2 and 3 <= n <= DEVICE_EIG_MAX_N and DEVICE_EIG
-    if dev_eig:
-        out = _pod_device_eig(X, G, colnorm, flag, normalize, num, tol, passes, want_vt, prof, t0)
-        if out is not None:
-            return out
-    Gh = G.cpu().numpy()
+    eig = _SmallEig(G, extra=(flag,))
     t1 = time.perf_counter()
-    if normalize and int(flag.item()) != 0:
+    if normalize and int(eig.extra[0]) != 0:
         # the reference divides by a zero norm and scipy.linalg.svd then rejects the NaNs (pod.py:32-38)
         raise ValueError("array must not contain infs or NaNs (zero-norm snapshot with normalize=True)")
-    lam, W = _eigh_desc(Gh)
-    t2 = time.perf_counter()
+    lam = eig.lam
     s = np.sqrt(np.clip(lam, 0.0, None))
     energy = _energy(s)
     r = truncation_rank(s, energy, num=num, tol=tol)
-    dinv = (1.0 / colnorm.cpu().numpy()) if normalize else None
-
+    deep = r > 0 and s[0] > 0 and s[r - 1] < TWO_PASS_RATIO * s[0]
     if passes is None:
-        passes = 2 if (r > 0 and s[0] > 0 and s[r - 1] < TWO_PASS_RATIO * s[0]) else 1
+        passes = "deflate" if deep else 1
 
     if passes == 1:
-        T = W[:, :r] * _inv_or_zero(s[:r])
-        if dinv is not None:
-            T = T * dinv[:, None]
-        Q = ops.gemm_nn(X, ops.to_device(T, X.device)) if r > 0 else X.new_zeros((X.shape[0], 0))
-        VT = np.ascontiguousarray(W[:, :r].T) if want_vt else None
-    else:
-        T1 = W if dinv is None else W * dinv[:, None]
-        Y = ops.gemm_nn(X, ops.to_device(T1, X.device))
-        G2 = allreduce(ops.gram(Y)).cpu().numpy()
+        if r > 0:
+            Z = eig.vectors(r)
+            Zs = (Z / colnorm[:, None] if normalize else Z) * ops.to_device(_inv_or_zero(s[:r]), X.device)[None, :]
+            Q = ops.gemm_nn(X, Zs.contiguous())
+            VT = np.ascontiguousarray(Z.cpu().numpy().T) if want_vt else None
+        else:
+            Q, VT = X.new_zeros((X.shape[0], 0)), (np.zeros((0, n)) if want_vt else None)
+    elif passes == 2:
+        W = eig.vectors(n)
+        Y = ops.gemm_nn(X, (W / colnorm[:, None] if normalize else W).contiguous())
+        G2 = _allreduce(ops.gram(Y), group).cpu().numpy()
         lam2, W2 = jacobi_eigh(G2)
         s = np.sqrt(np.clip(lam2, 0.0, None))
         energy = _energy(s)
         r = truncation_rank(s, energy, num=num, tol=tol)
         T2 = W2[:, :r] * _inv_or_zero(s[:r])
         Q = ops.gemm_nn(Y, ops.to_device(T2, X.device)) if r > 0 else X.new_zeros((X.shape[0], 0))
-        VT = np.ascontiguousarray((W @ W2[:, :r]).T) if want_vt else None
-    if prof:
-        torch.cuda.synchronize()
-        t3 = time.perf_counter()
-        LAST_TIMINGS["allreduce_scale_d2h_ms"] = 1e3 * (t1 - t0) - LAST_TIMINGS["gram_ms"]
-        LAST_TIMINGS["eig_host_ms"] = 1e3 * (t2 - t1)
-        LAST_TIMINGS["backproject_ms"] = 1e3 * (t3 - t2)
-        LAST_TIMINGS["total_ms"] = 1e3 * (t3 - t0)
-    return dict(Q=Q, s=s, energy=energy, VT=VT, r=r, passes=passes, colnorm=colnorm)
-
-
-def _pod_device_eig(X, G, colnorm, flag, normalize, num, tol, passes, want_vt, prof, t0):
-    """Single-pass POD with the n x n eigenproblem on the device (rt_sym_eig_values/_vectors) and a
-    k x k Rayleigh-Ritz polish.  Returns None when the spectrum asks for the two-pass path (the caller
-    continues on the host-eig route, which provides the full rotation)."""
-    import time
-
-    from scipy.linalg import eigh as small_eigh
-
-    n = G.shape[0]
-    lam_d, status = ops.sym_eig_values(G)
-    head = torch.cat([lam_d, status.to(torch.float64), flag.to(torch.float64)]).cpu().numpy()  # one D2H
-    t1 = time.perf_counter()
-    lam, eig_status, zero_norm = head[:n], int(head[n]), int(head[n + 1])
-    if normalize and zero_norm != 0:
-        raise ValueError("array must not contain infs or NaNs (zero-norm snapshot with normalize=True)")
-    if eig_status != 0:
-        raise _lib.RomtimeHipError("rt_sym_eig_values: inter-workgroup hand-off timed out")
-    s = np.sqrt(np.clip(lam, 0.0, None))
-    energy = _energy(s)
-    r = truncation_rank(s, energy, num=num, tol=tol)
-    if passes is None and r > 0 and s[0] > 0 and s[r - 1] < TWO_PASS_RATIO * s[0]:
-        return None
-    if r == 0:
-        Q = X.new_zeros((X.shape[0], 0))
-        VT = np.zeros((0, n)) if want_vt else None
+        VT = np.ascontiguousarray((W.cpu().numpy() @ W2[:, :r]).T) if want_vt else None
+    elif passes == "deflate":
+        Q, s, energy, r, VT, levels = _pod_deflated(X, eig, colnorm, normalize, num, tol, group, want_vt)
+        LAST_TIMINGS["levels"] = float(levels)
     else:
-        Z = ops.sym_eig_vectors(lam_d, r)                       # n x r
-        # inverse iteration resolves an eigenvector to ~eps ||G|| / gap: with every gap among the kept
-        # eigenvalues (and to the first discarded one) above RR_GAP * lam_1 that is <= 2e-12 and the
-        # vectors are used as they are; closer eigenvalues get the k x k Rayleigh-Ritz step on G
-        gaps = lam[:r] - lam[1:r + 1] if r < n else np.r_[lam[:r - 1] - lam[1:r], lam[r - 1]]
-        if gaps.min() >= RR_GAP * max(lam[0], 1e-300):
-            C, C_is_identity = None, True
-        else:
-            GZ = ops.gemm_nn(G, Z)
-            HS = torch.cat([ops.gemm_tn(Z, GZ), ops.gemm_tn(Z, Z)], dim=0).cpu().numpy()
-            H, S = 0.5 * (HS[:r] + HS[:r].T), 0.5 * (HS[r:] + HS[r:].T)
-            with _blas_threads(1):                                   # k x k: threads only burn the CPU quota
-                theta, C = small_eigh(H, S)                          # generalised Rayleigh-Ritz
-            theta, C = theta[::-1], C[:, ::-1]
-            if np.abs(theta - lam[:r]).max() > 1e-9 * max(lam[0], 1e-300):
-                raise _lib.RomtimeHipError("device eigenvectors failed the Rayleigh-Ritz cross-check")
-            C_is_identity = False
-        scale = _inv_or_zero(s[:r])
-        T2 = ops.to_device(np.ascontiguousarray(np.diag(scale) if C_is_identity else C * scale), X.device)
-        Zs = Z if not normalize else Z / colnorm[:, None]
-        if C_is_identity:
-            Q = ops.gemm_nn(X, (Zs * T2.diagonal()[None, :]).contiguous())
-        else:
-            Q = ops.gemm_nn(X, ops.gemm_nn(Zs.contiguous(), T2))
-        if want_vt:
-            Zh = Z.cpu().numpy()
-            VT = np.ascontiguousarray((Zh if C_is_identity else Zh @ C).T)
-        else:
-            VT = None
+        raise ValueError(f"passes must be None, 1, 2 or 'deflate', not {passes!r}")
     if prof:
         torch.cuda.synchronize()
         t3 = time.perf_counter()
         LAST_TIMINGS["allreduce_scale_eigvals_ms"] = 1e3 * (t1 - t0) - LAST_TIMINGS["gram_ms"]
         LAST_TIMINGS["eigvec_backproject_ms"] = 1e3 * (t3 - t1)
         LAST_TIMINGS["total_ms"] = 1e3 * (t3 - t0)
-        LAST_TIMINGS["eig_path"] = 1.0
-    return dict(Q=Q, s=s, energy=energy, VT=VT, r=r, passes=1, colnorm=colnorm)
+        LAST_TIMINGS["eig_on_device"] = float(eig.on_device)
+    return dict(Q=Q, s=s, energy=energy, VT=VT, r=r, passes=passes, colnorm=colnorm)
+
+
+MAX_LEVELS = 12
+
+
+def _pod_deflated(X, eig0, colnorm, normalize, num, tol, group, want_vt):
+    """Deep spectra without leaving the device: a Gram pass resolves the modes within TWO_PASS_RATIO of
+    the current largest singular value to ~eps; those are accepted, projected out of the snapshots
+    (X <- X - Q (Q^T X), an O(eps ||X||) perturbation - what dgesvd's backward stability allows too) and the
+    next level starts from a matrix whose largest singular value is >= 100x smaller.  Each level costs a
+    Gram pass, one small eigensolve and two tall-skinny GEMMs; modes come out with errors ~eps sigma_1 /
+    (sigma_i gap), dgesvd's own level (POD accuracy)."""
+    n = X.shape[1]
+    dev = X.device
+    total = float(np.sum(np.clip(eig0.lam, 0.0, None)))   # == trace(G0): the energy denominator
+    Xc, eig = None, eig0
+    s_acc, Q_acc, W_acc = [], [], []
+    levels = 0
+    while True:
+        levels += 1
+        sig = np.sqrt(np.clip(eig.lam, 0.0, None))
+        room = n - sum(len(x) for x in s_acc)
+        k = int(min(max(1, np.count_nonzero(sig >= TWO_PASS_RATIO * sig[0])), room)) if sig[0] > 0 else 0
+        if k > 0:
+            Z = eig.vectors(k)
+            src = X if Xc is None else Xc
+            scale = ops.to_device(_inv_or_zero(sig[:k]), dev)[None, :]
+            Zs = (Z / colnorm[:, None] if (normalize and Xc is None) else Z) * scale
+            Ql = ops.gemm_nn(src, Zs.contiguous())
+            s_acc.append(sig[:k])
+            Q_acc.append(Ql)
+            if want_vt:
+                W_acc.append(Z.cpu().numpy())
+        got = sum(len(x) for x in s_acc)
+        tail = sig[k:k + (n - got)]
+        s_full = np.concatenate(s_acc + [tail, np.zeros(max(0, n - got - len(tail)))])
+        ev = np.power(s_full, 2)
+        energy = np.cumsum(ev) / total
+        r = truncation_rank(s_full, energy, num=num, tol=tol)
+        if r <= got or k == 0 or got >= n or levels >= MAX_LEVELS or tail.size == 0 or tail[0] <= 0.0:
+            break
+        # deflate: X <- X - Q (Q^T X), twice (classical Gram-Schmidt needs the second sweep)
+        if Xc is None:
+            Xc = X / colnorm[None, :] if normalize else X.clone()
+        for _ in range(2):
+            C = _allreduce(ops.gemm_tn(Ql, Xc), group)  # Q^T X sums over the row slabs of all ranks
+            Xc = Xc - ops.gemm_nn(Ql, C)
+        G = _allreduce(ops.gram(Xc), group)
+        eig = _SmallEig(G)
+    Q = torch.cat(Q_acc, dim=1)[:, :r].contiguous() if (r > 0 and Q_acc) else X.new_zeros((X.shape[0], 0))
+    VT = np.ascontiguousarray(np.hstack(W_acc)[:, :r].T) if (want_vt and W_acc) else (np.zeros((0, n)) if want_vt else None)
+    return Q, s_full, energy, r, VT, levels
 
 
 def orth(snapshots, num=None, tol=None, normalize=True, return_VT=False, passes=None, group=None):

@@ -38,7 +38,7 @@ def _worker(rank, world, port, X, kwargs, ret):
 
 
 @pytest.mark.parametrize("kwargs", [dict(num=6, normalize=True), dict(tol=1 - 1e-9, normalize=False),
-                                    dict(normalize=True, passes=2), dict(normalize=False)])
+                                    dict(normalize=True, passes=2), dict(normalize=False), dict(normalize=True, passes="deflate", num=9)])
 def test_row_sharded_pod_matches_single_process(cpu_ops, kwargs):
     rng = np.random.RandomState(7)
     U0, _ = np.linalg.qr(rng.standard_normal((301, 12)))
