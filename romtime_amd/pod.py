@@ -230,6 +230,18 @@ def pod_device(X: torch.Tensor, num=None, tol=None, normalize=True, passes=None,
         LAST_TIMINGS["levels"] = float(levels)
     else:
         raise ValueError(f"passes must be None, 1, 2 or 'deflate', not {passes!r}")
+    # more snapshots than DoFs: the thin SVD of the reference has only min(N, n) singular values (pod.py:38)
+    n_rows = X.shape[0]
+    if group is not None and n_rows < n:  # only then can the global row count be below n
+        import torch.distributed as dist
+
+        cnt = torch.tensor([n_rows], dtype=torch.int64, device=X.device)
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+        n_rows = int(cnt.item())
+    if n_rows < n:
+        s, energy, r = s[:n_rows], energy[:n_rows], min(r, n_rows)
+        Q = Q[:, :r].contiguous()
+        VT = VT[:r] if VT is not None else None
     if prof:
         torch.cuda.synchronize()
         t3 = time.perf_counter()

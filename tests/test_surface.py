@@ -366,7 +366,7 @@ def check_orth_odd_shapes():
     from romtime_amd import orth
 
     rng = np.random.RandomState(11)
-    for N, n, kw in [(5, 2, {}), (50, 1, {}), (1000, 3, dict(num=2)), (37, 5, dict(tol=0.99)), (300, 17, dict(num=40)),
+    for N, n, kw in [(5, 2, {}), (50, 1, {}), (40, 60, dict(num=60)), (12, 30, {}), (1000, 3, dict(num=2)), (37, 5, dict(tol=0.99)), (300, 17, dict(num=40)),
                      (2000, 64, dict(num=10)), (9000, 130, dict(num=12, normalize=False))]:
         X = rng.standard_normal((N, n)) * 10.0 ** (-0.3 * np.arange(n))
         for arr in (np.ascontiguousarray(X), np.asfortranarray(X)):
