@@ -50,12 +50,13 @@ def _layout(t: torch.Tensor):
     return t, c, ROW_MAJOR
 
 
-def gram(X: torch.Tensor) -> torch.Tensor:
-    """G = X^T X (n x n). rt_gram."""
+def gram(X: torch.Tensor, out: torch.Tensor = None) -> torch.Tensor:
+    """G = X^T X (n x n). rt_gram.  ``out``: optional contiguous n x n tensor to write into."""
     ctx = Context.current()
     X, ld, lay = _layout(X)
     N, n = X.shape
-    G = torch.empty((n, n), dtype=torch.float64, device=X.device)
+    G = out if out is not None else torch.empty((n, n), dtype=torch.float64, device=X.device)
+    assert G.shape == (n, n) and G.is_contiguous()
     ctx.check(ctx.lib.rt_gram(ctx.handle, _ptr(X), N, n, ld, lay, _ptr(G)), "rt_gram")
     return G
 

@@ -186,14 +186,17 @@ def pod_device(X: torch.Tensor, num=None, tol=None, normalize=True, passes=None,
     ctx = _lib.Context.current() if X.is_cuda else None
     prof = bool(ctx is not None and _profiling(ctx))
     t0 = time.perf_counter()
-    G = ops.gram(X)
+    # G and the row count share one buffer, so a row-sharded run needs a single all-reduce
+    Gbuf = torch.empty(n * n + 1, dtype=torch.float64, device=X.device)
+    G = ops.gram(X, out=Gbuf[: n * n].view(n, n))
+    Gbuf[n * n:].fill_(float(X.shape[0]))
     if prof:
         LAST_TIMINGS.clear()
         LAST_TIMINGS["gram_kernel_ms"] = ctx.last_gemm_ms()
         LAST_TIMINGS["gram_ms"] = 1e3 * (time.perf_counter() - t0)
-    G = _allreduce(G, group)
+    _allreduce(Gbuf, group)
     colnorm, flag = ops.gram_scale(G, normalize)
-    eig = _SmallEig(G, extra=(flag,))
+    eig = _SmallEig(G, extra=(flag, Gbuf[n * n:]))
     t1 = time.perf_counter()
     if normalize and int(eig.extra[0]) != 0:
         # the reference divides by a zero norm and scipy.linalg.svd then rejects the NaNs (pod.py:32-38)
@@ -231,13 +234,7 @@ def pod_device(X: torch.Tensor, num=None, tol=None, normalize=True, passes=None,
     else:
         raise ValueError(f"passes must be None, 1, 2 or 'deflate', not {passes!r}")
     # more snapshots than DoFs: the thin SVD of the reference has only min(N, n) singular values (pod.py:38)
-    n_rows = X.shape[0]
-    if group is not None and n_rows < n:  # only then can the global row count be below n
-        import torch.distributed as dist
-
-        cnt = torch.tensor([n_rows], dtype=torch.int64, device=X.device)
-        dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
-        n_rows = int(cnt.item())
+    n_rows = int(round(float(eig.extra[1])))  # global row count (summed with G over the ranks)
     if n_rows < n:
         s, energy, r = s[:n_rows], energy[:n_rows], min(r, n_rows)
         Q = Q[:, :r].contiguous()

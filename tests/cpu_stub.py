@@ -27,8 +27,12 @@ def to_device_index(a, device=None):
     return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.int64)))
 
 
-def gram(X):
-    return (X.T @ X).contiguous()
+def gram(X, out=None):
+    G = (X.T @ X).contiguous()
+    if out is not None:
+        out.copy_(G)
+        return out
+    return G
 
 
 def gram_scale(G, normalize):
