@@ -68,6 +68,22 @@ struct Panel {
     }
   }
 
+  // interior panel (all KB rows and BT columns in range, 16-byte aligned pairs): no predicates, no branches
+  static __device__ __forceinline__ void load_full(d2 (&regs)[NL], const double* __restrict__ P, long ks, long ms,
+                                                   long k0, long m0, int tid) {
+#pragma unroll
+    for (int j = 0; j < NL; ++j) {
+      const int q = tid + NTHR * j;
+      if (!KC) {
+        const int kk = q / (BT / 2), i = (q % (BT / 2)) * 2;
+        regs[j] = *reinterpret_cast<const d2*>(P + (k0 + kk) * ks + (m0 + i));
+      } else {
+        const int i = q / (KB / 2), kk = (q % (KB / 2)) * 2;
+        regs[j] = *reinterpret_cast<const d2*>(P + (m0 + i) * ms + (k0 + kk));
+      }
+    }
+  }
+
   static __device__ __forceinline__ void store(const d2 (&regs)[NL], double* s, int tid) {
 #pragma unroll
     for (int j = 0; j < NL; ++j) {

@@ -49,7 +49,7 @@ __device__ const unsigned char kDiagTj[8][5] = {{0, 1, 2, 3, 1}, {2, 3, 2, 3, 3}
                                                 {6, 7, 4, 5, 6}, {7, 4, 5, 6, 7}, {5, 6, 7, 6, 0}, {7, 7, 0, 0, 0}};
 
 template <bool KC, bool DIAG>
-__global__ __launch_bounds__(GT, 2) void gram128_kernel(const GramParams p) {
+__global__ __launch_bounds__(GT, 4) void gram128_kernel(const GramParams p) {
   using P = Panel<BT, KC, GT>;
   extern __shared__ __attribute__((aligned(16))) double smem[];
   double* sA0 = smem;
@@ -87,6 +87,8 @@ __global__ __launch_bounds__(GT, 2) void gram128_kernel(const GramParams p) {
   }
 
   d2 ra[P::NL], rb[DIAG ? 1 : P::NL];
+  // interior tiles take the predicate-free loader for every stage that lies fully inside the K range
+  const bool interior = p.vec && (m0 + BT <= p.n) && (n0 + BT <= p.n);
   if (p.flags & 2) {
     // de-phase the two waves that share a SIMD: the odd hardware wave slot starts half a stage late
     const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | ((4 - 1) << 11));  // HW_REG_HW_ID[3:0] = wave_id
@@ -107,8 +109,13 @@ __global__ __launch_bounds__(GT, 2) void gram128_kernel(const GramParams p) {
     const bool more = (st + 1 < nstages) && !(p.flags & 4);  // flags & 4: timing experiment, no refills
     if (more) {
       const long k0 = kbeg + (long)(q0 + (st + 1) * S) * KB;
-      P::load(ra, p.X, p.ks, p.ms, k0, kend, m0, p.n, p.vec, tid);
-      if constexpr (!DIAG) P::load(rb, p.X, p.ks, p.ms, k0, kend, n0, p.n, p.vec, tid);
+      if (interior && k0 + KB <= kend) {
+        P::load_full(ra, p.X, p.ks, p.ms, k0, m0, tid);
+        if constexpr (!DIAG) P::load_full(rb, p.X, p.ks, p.ms, k0, n0, tid);
+      } else {
+        P::load(ra, p.X, p.ks, p.ms, k0, kend, m0, p.n, p.vec, tid);
+        if constexpr (!DIAG) P::load(rb, p.X, p.ks, p.ms, k0, kend, n0, p.n, p.vec, tid);
+      }
     }
     if (p.flags & 1) __builtin_amdgcn_s_setprio(1);
     if constexpr (DIAG) {
