@@ -55,7 +55,11 @@ int rt_gemm_strided(rt_ctx* ctx, const double* A, int64_t a_ks, int64_t a_ms, co
 // Specialised Gram kernel (gram_mfma.hip); RT_ERR_UNSUPPORTED means "use rt_gemm_strided".
 int rt_gram128(rt_ctx* ctx, const double* X, int64_t ks, int64_t ms, int64_t K, int64_t n, double* G);
 
-// Fused SpMM + V^T(.) projection (project_fused.hip); RT_ERR_UNSUPPORTED for r > 128.
-
+// Fused SpMM + V^T(.) projection (project_fused.hip); RT_ERR_UNSUPPORTED for r > 128.  `stage_table` is the
+// per-pattern table built by rt_project_stage_table (rt_project_stage_table_bytes(N) bytes of device memory), or
+// nullptr to have it built on every call.
+size_t rt_project_stage_table_bytes(int64_t N);
+int rt_project_stage_table(rt_ctx* ctx, const int64_t* indptr, const int64_t* indices, int64_t N, void* table);
 int rt_project_fused(rt_ctx* ctx, const int64_t* indptr, const int64_t* indices, const double* data, int64_t d_es,
-                     int64_t d_bs, int64_t B, int64_t N, const double* V, int64_t ldv, int64_t r, double* AN);
+                     int64_t d_bs, int64_t B, int64_t N, const double* V, int64_t ldv, int64_t r, double* AN,
+                     const void* stage_table = nullptr);

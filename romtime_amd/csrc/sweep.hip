@@ -87,7 +87,7 @@ extern "C" int rt_rom_bdf_sweep(rt_ctx* ctx, const rt_sweep_desc* d, double* uN_
                oKN = take(sizeof(double) * B * r * r), oRhs = take(sizeof(double) * B * r), oUn = take(sizeof(double) * B * r),
                oUm = take(sizeof(double) * B * r), oUh = take(sizeof(double) * B * N), oUp = take(sizeof(double) * B * N),
                oXT = take(sizeof(double) * r * B), oInfo = take(sizeof(int) * B),
-               oKv = take(sizeof(double) * B * nnz);
+               oKv = take(sizeof(double) * B * nnz), oTab = take(rt_project_stage_table_bytes(N));
   void* base = nullptr;
   int rc = rt_scratch2(ctx, off, &base);
   if (rc != RT_OK) return rc;
@@ -104,6 +104,7 @@ extern "C" int rt_rom_bdf_sweep(rt_ctx* ctx, const rt_sweep_desc* d, double* uN_
   double* xT = reinterpret_cast<double*>(b8 + oXT);
   int* info = reinterpret_cast<int*>(b8 + oInfo);
   double* kval = reinterpret_cast<double*>(b8 + oKv);
+  void* stage_table = b8 + oTab;  // per-pattern stage records of the fused projection, built once per sweep
 
   RT_HIP_CHECK(ctx, hipMemsetAsync(un, 0, sizeof(double) * B * r, st));
   RT_HIP_CHECK(ctx, hipMemsetAsync(unm1, 0, sizeof(double) * B * r, st));
@@ -112,8 +113,10 @@ extern "C" int rt_rom_bdf_sweep(rt_ctx* ctx, const rt_sweep_desc* d, double* uN_
   hipLaunchKernelGGL(sweep_rows_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st,
                      reinterpret_cast<const long*>(d->indptr), N, row_of);
   RT_HIP_CHECK(ctx, hipGetLastError());
+  rc = rt_project_stage_table(ctx, d->indptr, d->indices, N, stage_table);
+  if (rc != RT_OK) return rc;
   // M_N = V^T M V and f_N[f] = V^T f_f, once
-  rc = rt_project_fused(ctx, d->indptr, d->indices, d->mass_values, 1, 0, 1, N, d->V, r, r, MN);
+  rc = rt_project_fused(ctx, d->indptr, d->indices, d->mass_values, 1, 0, 1, N, d->V, r, r, MN, stage_table);
   if (rc != RT_OK) return rc;
   if (F) {
     // rhs_terms is F x N (each vector contiguous): A(k, i) = V[k][i], B(k, f) = rhs_terms[f][k]
@@ -128,7 +131,7 @@ extern "C" int rt_rom_bdf_sweep(rt_ctx* ctx, const rt_sweep_desc* d, double* uN_
                        Q ? d->term_coef + step * B * Q : nullptr, d->tril_values, row_of, uh, uhp, d->bdf2 ? 1 : 0, nnz,
                        N, second ? 1.5 : 1.0, d->dt, kval);
     RT_HIP_CHECK(ctx, hipGetLastError());
-    rc = rt_project_fused(ctx, d->indptr, d->indices, kval, 1, nnz, B, N, d->V, r, r, KN);
+    rc = rt_project_fused(ctx, d->indptr, d->indices, kval, 1, nnz, B, N, d->V, r, r, KN, stage_table);
     if (rc != RT_OK) return rc;
     const double c0 = d->bdf2 ? 2.0 : 1.0, c1 = d->bdf2 ? -0.5 : 0.0;  // u^{n-1} = 0 at step 0 reproduces BDF1
     // reference: step 0 of a BDF2 run uses M_N (2 u^0 - u^{-1}/2) with both zero (rom.py:451-458,921-924)

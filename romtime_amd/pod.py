@@ -186,6 +186,9 @@ def pod_device(X: torch.Tensor, num=None, tol=None, normalize=True, passes=None,
     ctx = _lib.Context.current() if X.is_cuda else None
     prof = bool(ctx is not None and _profiling(ctx))
     t0 = time.perf_counter()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if prof else None
+    if prof:
+        ev[0].record()
     # G and the row count share one buffer, so a row-sharded run needs a single all-reduce
     Gbuf = torch.empty(n * n + 1, dtype=torch.float64, device=X.device)
     G = ops.gram(X, out=Gbuf[: n * n].view(n, n))
@@ -195,6 +198,8 @@ def pod_device(X: torch.Tensor, num=None, tol=None, normalize=True, passes=None,
         LAST_TIMINGS["gram_kernel_ms"] = ctx.last_gemm_ms()
         LAST_TIMINGS["gram_ms"] = 1e3 * (time.perf_counter() - t0)
     _allreduce(Gbuf, group)
+    if prof:
+        ev[1].record()  # the current stream waits for the collective, so this event closes Gram + all-reduce
     colnorm, flag = ops.gram_scale(G, normalize)
     eig = _SmallEig(G, extra=(flag, Gbuf[n * n:]))
     t1 = time.perf_counter()
@@ -245,6 +250,7 @@ def pod_device(X: torch.Tensor, num=None, tol=None, normalize=True, passes=None,
         LAST_TIMINGS["allreduce_scale_eigvals_ms"] = 1e3 * (t1 - t0) - LAST_TIMINGS["gram_ms"]
         LAST_TIMINGS["eigvec_backproject_ms"] = 1e3 * (t3 - t1)
         LAST_TIMINGS["total_ms"] = 1e3 * (t3 - t0)
+        LAST_TIMINGS["gram_allreduce_ms"] = ev[0].elapsed_time(ev[1])
         LAST_TIMINGS["eig_on_device"] = float(eig.on_device)
     return dict(Q=Q, s=s, energy=energy, VT=VT, r=r, passes=passes, colnorm=colnorm)
 
