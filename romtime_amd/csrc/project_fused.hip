@@ -2,22 +2,30 @@
 // (project_csr, utils.py:96-113; MDEIM.project_basis, mdeim.py:153-192; the online direct path,
 // rom.py:149-153) without materialising A_b V in HBM.
 //
-// One workgroup owns one (value-vector b, DoF-range) pair.  Per 16-row stage it
-//   * finds the column window of the stage's rows and, when it spans <= 64 DoFs (banded FE operators),
-//     copies those V rows into LDS once; the stage's own 16 rows inside it are the A operand,
-//   * builds the 16 rows of (A_b V) on the fly: row k = sum_e a_b[e] V[col_e][:], read from the LDS
-//     window (or gathered through L1/L2 when the window is too wide), written into the LDS image of
-//     the B operand,
-//   * accumulates the r x r product on the FP64 matrix cores: the ceil(r/16)^2 MFMA tiles are dealt
-//     round-robin to the 8 waves, operands read from LDS at run-time offsets, so r = 80 costs 25
-//     tiles (not the 36 of a padded 96 x 96 tile).
+// One workgroup (8 waves) owns one (value-vector b, DoF-range) pair and walks the range in stages of 32 rows:
+//   * the column window of the stage's rows (<= 48 DoFs for banded FE operators) is copied from V into LDS
+//     once; the stage's own 32 rows inside it are the A operand of the product,
+//   * the 32 rows of (A_b V) are built on the fly, row k = sum_e a_b[e] V[col_e][:], out of that window
+//     (or gathered through L1/L2 when the window is too wide) into the LDS image of the B operand,
+//   * the r x r product is accumulated on the FP64 matrix cores; every wave owns fixed rectangular blocks of
+//     the ceil(r/16)^2 grid of 16x16 tiles (compile-time layout per wave), so r = 80 costs 25 tiles, not the
+//     36 of a padded 96 x 96 tile, and a k-step of an ni x nj block costs ni + nj LDS reads.
 // Partial r x r blocks of the DoF-ranges go to slabs and are summed in a fixed order.
 // HBM traffic: the value vectors once (8 nnz B bytes) + V once; the unfused path moved 16 N r B more.
+//
+// What shapes the code: on gfx950 a wave's FP64 MFMA blocks the VALU of its SIMD for the 64 cycles it runs --
+// measured with rt_bench_mfma_f64's co-issue probe, MFMAs of one wave and integer VALU work of another wave on
+// the same SIMD take exactly the sum of their times.  Every VALU instruction therefore costs matrix-core time,
+// and a producer/consumer split of the waves buys nothing (tried: slower).  So all strides and tile offsets are
+// compile-time (LDS accesses use immediate offsets), window loads are 16-byte with per-thread offsets computed
+// once, each staged entry carries its window-row byte offset, and the stage records make every global load of
+// stage s+1 independent of any other load (they are all in flight while stage s computes).
 #include "common.h"
 
-#include <utility>
+#include <cstdlib>
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -26,8 +34,9 @@ constexpr int PT = 512;       // threads (8 waves)
 constexpr int RMAX = 128;
 constexpr int WROWS = 48;     // V rows kept in LDS per stage (banded FE operators touch ~PK + 2*bandwidth)
 constexpr int EMAX = PT;      // entries of one stage staged through LDS (one per thread)
-constexpr int WREG = WROWS / 4;  // window doubles per thread in flight: column tid % 128, rows tid / 128 + 4 i
-constexpr int MAXT = 8;       // MFMA tiles per wave at most (r = 128: 64 tiles on 8 waves)
+
+// == 16 (mod 32) doubles: conflict-free ds_read_b64 of the MFMA operands
+__host__ __device__ constexpr int stride_of(int tr) { return ((16 * tr + 31) / 32) * 32 + 16; }
 
 // Everything a stage needs to start its loads, in one wave-uniform 32-byte record (one scalar load, issued a
 // whole stage ahead): entry range [e0, e1) of the stage's rows and their column window [lo, hi];
@@ -36,6 +45,12 @@ struct StageRec {
   long e0, e1;
   int lo, hi;
   int pad0, pad1;
+};
+
+struct Entry {  // staged entry: value and byte offset of its V row inside the LDS window
+  double val;
+  int rowoff;
+  int pad;
 };
 
 struct ProjParams {
@@ -47,11 +62,8 @@ struct ProjParams {
   long ldv;
   double* slab;        // [B][S][r*r]
   long N, k_per_split;
-  int r, B, S, tr, stride;
+  int r, B, S;
   const StageRec* rec;  // [stages]
-  // MFMA tiles of each wave, grouped in strips that share the A operand (same tile row): one byte (i << 4 | j)
-  // per tile, 0xff = none
-  unsigned long long tiles[8];
 };
 
 __global__ void project_stages_kernel(const long* __restrict__ indptr, const long* __restrict__ indices, long N,
@@ -77,64 +89,149 @@ __global__ void project_stages_kernel(const long* __restrict__ indptr, const lon
   rec[st] = o;
 }
 
-// Software-pipelined: while stage s is computed out of LDS, the entries (column, value), the per-row entry
-// ranges and the V-row window of stage s+1 are in flight into registers (their addresses come from the stage
-// record fetched during stage s-1, so no load waits on another load); they are written to LDS after the MFMAs.
-template <int TR, int PACC>  // TR = ceil(r/16), PACC = most MFMA tiles any wave owns
-__global__ __launch_bounds__(PT, TR <= 5 ? 4 : 2) void project_fused_kernel(const ProjParams p) {
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  double* sW = sm;                             // [WROWS][stride]  window of V rows
-  double* sB = sm + (size_t)WROWS * p.stride;  // [PK][stride]
-  double* sVal = sB + (size_t)PK * p.stride;   // [EMAX] values of the stage's entries
-  int* sCol = reinterpret_cast<int*>(sVal + EMAX);  // [EMAX] window-relative columns
+// Tile layout: wave w owns up to two rectangular blocks (rows i0..i0+ni-1 x columns j0..j0+nj-1 of the tile
+// grid).  Waves w and w + 4 share a SIMD; the layouts balance MFMA work per SIMD.
+struct Blk { int i0, ni, j0, nj; };
+template <int TR> struct Layout;
+#define NOBLK {0, 0, 0, 0}
+template <> struct Layout<1> { static constexpr Blk blk[8][2] = {{{0,1,0,1},NOBLK}, {NOBLK,NOBLK}, {NOBLK,NOBLK}, {NOBLK,NOBLK}, {NOBLK,NOBLK}, {NOBLK,NOBLK}, {NOBLK,NOBLK}, {NOBLK,NOBLK}}; };
+template <> struct Layout<2> { static constexpr Blk blk[8][2] = {{{0,1,0,1},NOBLK}, {{0,1,1,1},NOBLK}, {{1,1,0,1},NOBLK}, {{1,1,1,1},NOBLK}, {NOBLK,NOBLK}, {NOBLK,NOBLK}, {NOBLK,NOBLK}, {NOBLK,NOBLK}}; };
+template <> struct Layout<3> { static constexpr Blk blk[8][2] = {{{0,1,0,3},NOBLK}, {{1,1,0,2},NOBLK}, {{1,2,2,1},NOBLK}, {{2,1,0,2},NOBLK}, {NOBLK,NOBLK}, {NOBLK,NOBLK}, {NOBLK,NOBLK}, {NOBLK,NOBLK}}; };
+template <> struct Layout<4> { static constexpr Blk blk[8][2] = {{{0,1,0,2},NOBLK}, {{0,1,2,2},NOBLK}, {{1,1,0,2},NOBLK}, {{1,1,2,2},NOBLK}, {{2,1,0,2},NOBLK}, {{2,1,2,2},NOBLK}, {{3,1,0,2},NOBLK}, {{3,1,2,2},NOBLK}}; };
+template <> struct Layout<5> { static constexpr Blk blk[8][2] = {{{0,2,0,2},NOBLK}, {{0,2,2,2},NOBLK}, {{2,2,0,2},NOBLK}, {{2,2,2,2},NOBLK}, {{4,1,0,3},NOBLK}, {{0,2,4,1},NOBLK}, {{2,2,4,1},NOBLK}, {{4,1,3,2},NOBLK}}; };
+template <> struct Layout<6> { static constexpr Blk blk[8][2] = {{{0,2,0,3},NOBLK}, {{0,2,3,3},NOBLK}, {{2,2,0,3},NOBLK}, {{2,2,3,3},NOBLK}, {{4,1,0,3},NOBLK}, {{4,1,3,3},NOBLK}, {{5,1,0,3},NOBLK}, {{5,1,3,3},NOBLK}}; };
+template <> struct Layout<7> { static constexpr Blk blk[8][2] = {{{0,3,0,3},NOBLK}, {{0,3,3,3},NOBLK}, {{3,3,0,3},NOBLK}, {{3,3,3,3},NOBLK}, {{0,3,6,1},NOBLK}, {{3,3,6,1},NOBLK}, {{6,1,0,4},NOBLK}, {{6,1,4,3},NOBLK}}; };
+template <> struct Layout<8> { static constexpr Blk blk[8][2] = {{{0,2,0,4},NOBLK}, {{0,2,4,4},NOBLK}, {{2,2,0,4},NOBLK}, {{2,2,4,4},NOBLK}, {{4,2,0,4},NOBLK}, {{4,2,4,4},NOBLK}, {{6,2,0,4},NOBLK}, {{6,2,4,4},NOBLK}}; };
+#undef NOBLK
+
+template <int TR>
+constexpr bool layout_covers() {
+  int seen[8][8] = {};
+  for (int w = 0; w < 8; ++w)
+    for (int q = 0; q < 2; ++q) {
+      const Blk b = Layout<TR>::blk[w][q];
+      for (int i = b.i0; i < b.i0 + b.ni; ++i)
+        for (int j = b.j0; j < b.j0 + b.nj; ++j) ++seen[i][j];
+    }
+  for (int i = 0; i < TR; ++i)
+    for (int j = 0; j < TR; ++j)
+      if (seen[i][j] != 1) return false;
+  return true;
+}
+static_assert(layout_covers<1>() && layout_covers<2>() && layout_covers<3>() && layout_covers<4>() &&
+                  layout_covers<5>() && layout_covers<6>() && layout_covers<7>() && layout_covers<8>(),
+              "every output tile belongs to exactly one wave");
+
+// One k-step (4 rows of the stage) of an NI x NJ block: NI + NJ LDS reads at immediate offsets, NI*NJ MFMAs.
+template <int STRIDE, int NI, int NJ>
+__device__ __forceinline__ void block_step(const double* lA, const double* lB, int k4, int i0, int j0,
+                                           d4 (&acc)[NI * NJ > 0 ? NI * NJ : 1]) {
+  if constexpr (NI * NJ > 0) {
+    double a[NI], bq[NJ];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) a[i] = lA[k4 * 4 * STRIDE + 16 * (i0 + i)];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) bq[j] = lB[k4 * 4 * STRIDE + 16 * (j0 + j)];
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        acc[i * NJ + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bq[j], acc[i * NJ + j], 0, 0, 0);
+  }
+}
+
+template <int NI, int NJ>
+__device__ __forceinline__ void block_store(double* out, int r, int i0, int j0, int l4, int l15,
+                                            const d4 (&acc)[NI * NJ > 0 ? NI * NJ : 1]) {
+  if constexpr (NI * NJ > 0) {
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int row = 16 * (i0 + i) + l4 + 4 * c, col = 16 * (j0 + j) + l15;
+          if (row < r && col < r) out[(long)row * r + col] = acc[i * NJ + j][c];
+        }
+  }
+}
+
+// The whole stage loop for wave W (compile-time tile blocks).  Software-pipelined: while stage s is computed
+// out of LDS, the entries, the per-row entry ranges and the V-row window of stage s+1 are in flight into
+// registers (their addresses come from the stage record fetched during stage s-1, so no load waits on another
+// load); they are written to LDS after the MFMAs of stage s.
+template <int TR, int W>
+__device__ __forceinline__ void project_wave(const ProjParams& p, double* sm) {
+  constexpr int STRIDE = stride_of(TR);
+  constexpr int rp = TR * 16;
+  constexpr int PAIRS = rp / 2;                               // d2 pairs per window row
+  constexpr int NW = (WROWS * PAIRS + PT - 1) / PT;           // window pairs per thread
+  constexpr Blk b0 = Layout<TR>::blk[W][0], b1 = Layout<TR>::blk[W][1];
+  constexpr int N0 = b0.ni * b0.nj, N1 = b1.ni * b1.nj;
+  double* sW = sm;                                            // [WROWS][STRIDE]  window of V rows
+  double* sB = sm + WROWS * STRIDE;                           // [PK][STRIDE]     rows of A_b V
+  Entry* sEnt = reinterpret_cast<Entry*>(sB + PK * STRIDE);   // [EMAX]
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, l4 = lane >> 4;
   const int b = blockIdx.x % p.B, s = blockIdx.x / p.B;
-  const int r = p.r, stride = p.stride;
+  const int r = p.r;
   const long kbeg = (long)s * p.k_per_split;
   const long kend = (kbeg + p.k_per_split < p.N) ? kbeg + p.k_per_split : p.N;
   const double* dat = p.data + (long)b * p.d_bs;
+  const bool vec2 = ((p.ldv & 1) == 0) && ((reinterpret_cast<size_t>(p.V) & 15) == 0);
 
-  d4 acc[PACC];
-  int ti[PACC], tj[PACC];
-  const unsigned long long tl = p.tiles[wid];
-  int ntl = 0;
+  d4 acc0[N0 > 0 ? N0 : 1], acc1[N1 > 0 ? N1 : 1];
 #pragma unroll
-  for (int q = 0; q < PACC; ++q) {
-    acc[q] = d4{0.0, 0.0, 0.0, 0.0};
-    const unsigned t = (unsigned)(tl >> (8 * q)) & 0xffu;
-    ti[q] = (int)(t >> 4) * 16;
-    tj[q] = (int)(t & 15u) * 16;
-    if (t != 0xffu) ntl = q + 1;
+  for (int q = 0; q < (N0 > 0 ? N0 : 1); ++q) acc0[q] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int q = 0; q < (N1 > 0 ? N1 : 1); ++q) acc1[q] = d4{0.0, 0.0, 0.0, 0.0};
+
+  // per-thread constants of the window copy: pair q of the thread sits at row w_row[q], columns 2 cp, 2 cp + 1
+  int w_goff[NW], w_loff[NW], w_row[NW];
+  bool w_c0[NW], w_c1[NW];
+#pragma unroll
+  for (int q = 0; q < NW; ++q) {
+    const int pidx = tid + PT * q;
+    const int row = pidx / PAIRS, cp = pidx % PAIRS;
+    w_row[q] = (row < WROWS) ? row : (1 << 20);   // never < nrow
+    w_goff[q] = row * (int)p.ldv + 2 * cp;
+    w_loff[q] = row * STRIDE + 2 * cp;
+    w_c0[q] = 2 * cp < r;
+    w_c1[q] = 2 * cp + 1 < r;
   }
-  constexpr int rp = TR * 16;              // padded width
-  constexpr int CG = PT / PK;              // column groups of the B-operand mapping (PK rows x CG groups)
-  constexpr int NCOL = TR;                 // columns per thread: jg, jg + CG, ...
-  static_assert(CG == 16, "one thread column per 16-wide tile column");
-  const int kk = tid / CG, jg = tid % CG;
+  const int kk = tid >> 4, jg = tid & 15;  // gather mapping: row kk of the stage, columns jg + 16 c
 
   // registers of the stage in flight
-  const int wrow = tid >> 7, wcol = tid & 127;
-  double wreg[WREG];
+  d2 wreg[NW];
   double vreg = 0.0;
   int creg = 0, nb_lo = 0, nb_hi = 0;
-  StageRec rn{};  // record of the stage in flight
+  StageRec rn{};
 
   auto fetch = [&](long k0, const StageRec& rc) {  // issue the loads of stage k0 (no LDS access, no dependent load)
     rn = rc;
     const long k1 = (k0 + PK < kend) ? k0 + PK : kend;
     const int nrow = (rc.hi >= 0) ? (rc.hi - rc.lo + 1) : (int)(k1 - k0);
-    const double* vsrc = p.V + (long)(rc.lo + wrow) * p.ldv + wcol;
+    const double* vbase = p.V + (long)rc.lo * p.ldv;  // wave-uniform
 #pragma unroll
-    for (int i = 0; i < WREG; ++i)  // thread -> column wcol, rows wrow + 4 i
-      wreg[i] = (wrow + 4 * i < nrow && wcol < r) ? vsrc[(long)(4 * i) * p.ldv] : 0.0;
+    for (int q = 0; q < NW; ++q) {
+      d2 v{0.0, 0.0};
+      if (w_row[q] < nrow) {
+        const double* src = vbase + w_goff[q];
+        if (vec2 && w_c1[q]) {
+          v = *reinterpret_cast<const d2*>(src);
+        } else {
+          if (w_c0[q]) v.x = src[0];
+          if (w_c1[q]) v.y = src[1];
+        }
+      }
+      wreg[q] = v;
+    }
     if (rc.hi >= 0) {
       const long e = rc.e0 + tid;
       const bool v = e < rc.e1;
       vreg = v ? dat[e * p.d_es] : 0.0;
       creg = v ? (int)p.indices[e] - rc.lo : 0;
-      const long kr = k0 + kk;  // entry range of this thread's row, low words (the stage holds < 2^31 entries)
+      const long kr = k0 + kk;  // entry range of this thread's row, low words (a stage holds < 2^31 entries)
       const bool rv = kr < kend;
       nb_lo = rv ? (int)p.indptr[kr] : 0;
       nb_hi = rv ? (int)p.indptr[kr + 1] : 0;
@@ -142,12 +239,14 @@ __global__ __launch_bounds__(PT, TR <= 5 ? 4 : 2) void project_fused_kernel(cons
   };
   int c_lo = 0, c_hi = -1, row_base = 0, row_cnt = 0;
   auto commit = [&]() {  // registers -> LDS
-    if (wcol < rp) {
 #pragma unroll
-      for (int i = 0; i < WREG; ++i) sW[(wrow + 4 * i) * stride + wcol] = wreg[i];
-    }
-    sVal[tid] = vreg;
-    sCol[tid] = creg;
+    for (int q = 0; q < NW; ++q)
+      if (w_row[q] < WROWS) *reinterpret_cast<d2*>(sW + w_loff[q]) = wreg[q];
+    Entry en;
+    en.val = vreg;
+    en.rowoff = creg * STRIDE * (int)sizeof(double);
+    en.pad = 0;
+    sEnt[tid] = en;
     c_lo = rn.lo;
     c_hi = rn.hi;
     row_base = nb_lo - (int)rn.e0;
@@ -164,6 +263,9 @@ __global__ __launch_bounds__(PT, TR <= 5 ? 4 : 2) void project_fused_kernel(cons
   }
   __syncthreads();
 
+  const char* sWc = reinterpret_cast<const char*>(sW) + jg * sizeof(double);
+  double* brow = sB + kk * STRIDE + jg;
+  const double* lB = sB + l4 * STRIDE + l15;
   long st = st0;
   for (long k0 = kbeg; k0 < kend; k0 += PK, ++st) {
     const bool more = (k0 + PK < kend);
@@ -172,48 +274,39 @@ __global__ __launch_bounds__(PT, TR <= 5 ? 4 : 2) void project_fused_kernel(cons
       if (k0 + 2 * PK < kend) r2 = p.rec[st + 2];   // for the next iteration
       fetch(k0 + PK, r1);
     }
-    const bool windowed = (c_hi >= 0);
-    const int abase = (int)(k0 - c_lo);  // LDS row of DoF k0 (0 when not windowed)
     // B operand: rows of A_b V
     {
-      const long k = k0 + kk;
-      double o[NCOL];
+      double o[TR];
 #pragma unroll
-      for (int c = 0; c < NCOL; ++c) o[c] = 0.0;
-      if (windowed) {
+      for (int c = 0; c < TR; ++c) o[c] = 0.0;
+      if (c_hi >= 0) {
         for (int q = 0; q < row_cnt; ++q) {
-          const double a = sVal[row_base + q];
-          const double* vr = sW + sCol[row_base + q] * stride + jg;
+          const Entry en = sEnt[row_base + q];
+          const double* vr = reinterpret_cast<const double*>(sWc + en.rowoff);
 #pragma unroll
-          for (int c = 0; c < NCOL; ++c) o[c] = fma(a, vr[CG * c], o[c]);
+          for (int c = 0; c < TR; ++c) o[c] = fma(en.val, vr[16 * c], o[c]);
         }
-      } else if (k < kend) {
+      } else if (k0 + kk < kend) {
+        const long k = k0 + kk;
         const long e0 = p.indptr[k], e1 = p.indptr[k + 1];
         for (long e = e0; e < e1; ++e) {
           const double a = dat[e * p.d_es];
           const double* vr = p.V + p.indices[e] * p.ldv;
 #pragma unroll
-          for (int c = 0; c < NCOL; ++c)
-            if (jg + CG * c < r) o[c] = fma(a, vr[jg + CG * c], o[c]);
+          for (int c = 0; c < TR; ++c)
+            if (jg + 16 * c < r) o[c] = fma(a, vr[jg + 16 * c], o[c]);
         }
       }
-      double* row = sB + kk * stride + jg;
 #pragma unroll
-      for (int c = 0; c < NCOL; ++c) row[CG * c] = o[c];
+      for (int c = 0; c < TR; ++c) brow[16 * c] = o[c];
     }
     __syncthreads();
-    const double* cA = sW + abase * stride;
-#pragma unroll 1  // keeps the LDS operand loads of one k-step (not four) in flight
-    for (int k4 = 0; k4 < PK / 4; ++k4) {
-      const int rowoff = (k4 * 4 + l4) * stride + l15;
-      double a = 0.0;
+    if constexpr (N0 > 0) {
+      const double* lA = sW + ((int)(k0 - c_lo) + l4) * STRIDE + l15;  // LDS row of DoF k0 (+ this lane's k)
 #pragma unroll
-      for (int q = 0; q < PACC; ++q) {
-        if (q < ntl) {  // wave-uniform
-          if (q == 0 || ti[q] != ti[q - 1]) a = cA[rowoff + ti[q]];  // strips share the A operand
-          const double bb = sB[rowoff + tj[q]];
-          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bb, acc[q], 0, 0, 0);
-        }
+      for (int k4 = 0; k4 < PK / 4; ++k4) {
+        block_step<STRIDE, b0.ni, b0.nj>(lA, lB, k4, b0.i0, b0.j0, acc0);
+        block_step<STRIDE, b1.ni, b1.nj>(lA, lB, k4, b1.i0, b1.j0, acc1);
       }
     }
     __syncthreads();
@@ -221,14 +314,27 @@ __global__ __launch_bounds__(PT, TR <= 5 ? 4 : 2) void project_fused_kernel(cons
     __syncthreads();
   }
   double* out = p.slab + ((long)b * p.S + s) * ((long)r * r);
-#pragma unroll
-  for (int q = 0; q < PACC; ++q) {
-    if (q >= ntl) continue;
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int row = ti[q] + l4 + 4 * c, col = tj[q] + l15;
-      if (row < r && col < r) out[(long)row * r + col] = acc[q][c];
-    }
+  block_store<b0.ni, b0.nj>(out, r, b0.i0, b0.j0, l4, l15, acc0);
+  block_store<b1.ni, b1.nj>(out, r, b1.i0, b1.j0, l4, l15, acc1);
+}
+
+template <int TR>
+__global__ __launch_bounds__(PT, TR <= 5 ? 4 : 2) void project_fused_kernel(const ProjParams p) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  // a short last stage lets the A operand reach rows past the window (they only meet zero rows of B, but must be
+  // finite): no LDS word is ever read uninitialised
+  constexpr int words = (WROWS + PK) * stride_of(TR);
+  for (int i = threadIdx.x; i < words; i += PT) sm[i] = 0.0;
+  __syncthreads();
+  switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {  // one code path per wave: its tiles are constants
+    case 0: project_wave<TR, 0>(p, sm); break;
+    case 1: project_wave<TR, 1>(p, sm); break;
+    case 2: project_wave<TR, 2>(p, sm); break;
+    case 3: project_wave<TR, 3>(p, sm); break;
+    case 4: project_wave<TR, 4>(p, sm); break;
+    case 5: project_wave<TR, 5>(p, sm); break;
+    case 6: project_wave<TR, 6>(p, sm); break;
+    default: project_wave<TR, 7>(p, sm); break;
   }
 }
 
@@ -245,52 +351,6 @@ __global__ void project_reduce_kernel(const double* __restrict__ slab, int S, lo
 
 }  // namespace
 
-// MFMA tiles -> waves.  Each tile row is cut into strips of <= 3 tiles that share the A operand (LDS reads per
-// k-step: 1 + len instead of 2 len), strips are dealt longest-first to the least loaded wave, and the waves are
-// ordered so that the pairs (w, w + 4), which share a SIMD, carry balanced MFMA work.
-static void assign_tiles(ProjParams& p) {
-  const int TR = p.tr;
-  struct Strip { int i, j0, len; };
-  Strip strips[8 * 3];
-  int ns = 0;
-  const int per_row = (TR + 2) / 3;
-  for (int i = 0; i < TR; ++i) {
-    int j0 = 0;
-    for (int q = 0; q < per_row; ++q) {
-      const int len = TR / per_row + (q < TR % per_row ? 1 : 0);
-      strips[ns++] = Strip{i, j0, len};
-      j0 += len;
-    }
-  }
-  for (int a = 1; a < ns; ++a)  // stable insertion sort, longest first
-    for (int c = a; c > 0 && strips[c].len > strips[c - 1].len; --c) std::swap(strips[c], strips[c - 1]);
-  int load[8] = {0}, cnt[8] = {0};
-  unsigned char li[8][MAXT], lj[8][MAXT];
-  for (int a = 0; a < ns; ++a) {
-    int w = 0;
-    for (int c = 1; c < 8; ++c)
-      if (load[c] < load[w]) w = c;
-    for (int q = 0; q < strips[a].len; ++q) {
-      li[w][cnt[w]] = (unsigned char)strips[a].i;
-      lj[w][cnt[w]] = (unsigned char)(strips[a].j0 + q);
-      ++cnt[w];
-    }
-    load[w] += strips[a].len;
-  }
-  int order[8] = {0, 1, 2, 3, 4, 5, 6, 7};
-  for (int a = 1; a < 8; ++a)
-    for (int c = a; c > 0 && load[order[c]] > load[order[c - 1]]; --c) std::swap(order[c], order[c - 1]);
-  for (int w = 0; w < 8; ++w) {
-    const int src = (w < 4) ? order[w] : order[7 - (w - 4)];  // heaviest with lightest on one SIMD
-    unsigned long long packed = 0;
-    for (int q = 0; q < MAXT; ++q) {
-      const unsigned long long t = q < cnt[src] ? (unsigned long long)((li[src][q] << 4) | lj[src][q]) : 0xffull;
-      packed |= t << (8 * q);
-    }
-    p.tiles[w] = packed;
-  }
-}
-
 size_t rt_project_stage_table_bytes(int64_t N) { return sizeof(StageRec) * (size_t)((N + PK - 1) / PK); }
 
 int rt_project_stage_table(rt_ctx* ctx, const int64_t* indptr, const int64_t* indices, int64_t N, void* table) {
@@ -302,15 +362,16 @@ int rt_project_stage_table(rt_ctx* ctx, const int64_t* indptr, const int64_t* in
   return RT_OK;
 }
 
-template <int TR, int PACC>
-static int launch_fused(rt_ctx* ctx, const ProjParams& p, unsigned grid, size_t lds) {
+template <int TR>
+static int launch_fused(rt_ctx* ctx, const ProjParams& p, unsigned grid) {
+  const size_t lds = sizeof(double) * (size_t)(WROWS + PK) * stride_of(TR) + sizeof(Entry) * EMAX;
   static bool attr_set = false;
   if (!attr_set) {
-    RT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&project_fused_kernel<TR, PACC>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024));
+    RT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&project_fused_kernel<TR>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL((project_fused_kernel<TR, PACC>), dim3(grid), dim3(PT), lds, ctx->stream, p);
+  hipLaunchKernelGGL((project_fused_kernel<TR>), dim3(grid), dim3(PT), lds, ctx->stream, p);
   RT_HIP_CHECK(ctx, hipGetLastError());
   return RT_OK;
 }
@@ -321,15 +382,13 @@ int rt_project_fused(rt_ctx* ctx, const int64_t* indptr, const int64_t* indices,
                      int64_t d_bs, int64_t B, int64_t N, const double* V, int64_t ldv, int64_t r, double* AN,
                      const void* stage_table) {
   if (r > RMAX) return RT_ERR_UNSUPPORTED;
+  if ((int64_t)WROWS * ldv + RMAX >= (1LL << 31)) return RT_ERR_UNSUPPORTED;  // 32-bit window offsets
   ProjParams p;
   p.indptr = reinterpret_cast<const long*>(indptr);
   p.indices = reinterpret_cast<const long*>(indices);
   p.data = data; p.d_es = d_es; p.d_bs = d_bs;
   p.V = V; p.ldv = ldv; p.N = N; p.r = (int)r; p.B = (int)B;
-  p.tr = (int)((r + 15) / 16);
-  const int rp = p.tr * 16;
-  p.stride = ((rp + 31) / 32) * 32 + 16;  // == 16 (mod 32): conflict-free ds_read_b64 of the MFMA operands
-  assign_tiles(p);
+  const int tr = (int)((r + 15) / 16), rp = tr * 16;
   const long slots = 4L * ctx->num_cus;   // a few workgroups per CU so that gather and MFMA phases overlap
   long S = (slots + B - 1) / B;
   const long stages = (N + PK - 1) / PK;
@@ -351,7 +410,6 @@ int rt_project_fused(rt_ctx* ctx, const int64_t* indptr, const int64_t* indices,
     if (rc != RT_OK) return rc;
     p.rec = static_cast<const StageRec*>(table);
   }
-  const size_t lds = sizeof(double) * ((size_t)(WROWS + PK) * p.stride + EMAX) + sizeof(int) * EMAX;
   if (ctx->profile) {
     if (!ctx->ev0) {
       RT_HIP_CHECK(ctx, hipEventCreate(&ctx->ev0));
@@ -360,15 +418,15 @@ int rt_project_fused(rt_ctx* ctx, const int64_t* indptr, const int64_t* indices,
     RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   }
   const unsigned grid = (unsigned)(B * S);
-  switch (p.tr) {  // second argument = the most tiles assign_tiles gives one wave
-    case 1: rc = launch_fused<1, 1>(ctx, p, grid, lds); break;
-    case 2: rc = launch_fused<2, 2>(ctx, p, grid, lds); break;
-    case 3: rc = launch_fused<3, 3>(ctx, p, grid, lds); break;
-    case 4: rc = launch_fused<4, 2>(ctx, p, grid, lds); break;
-    case 5: rc = launch_fused<5, 4>(ctx, p, grid, lds); break;
-    case 6: rc = launch_fused<6, 6>(ctx, p, grid, lds); break;
-    case 7: rc = launch_fused<7, 7>(ctx, p, grid, lds); break;
-    default: rc = launch_fused<8, 8>(ctx, p, grid, lds); break;
+  switch (tr) {
+    case 1: rc = launch_fused<1>(ctx, p, grid); break;
+    case 2: rc = launch_fused<2>(ctx, p, grid); break;
+    case 3: rc = launch_fused<3>(ctx, p, grid); break;
+    case 4: rc = launch_fused<4>(ctx, p, grid); break;
+    case 5: rc = launch_fused<5>(ctx, p, grid); break;
+    case 6: rc = launch_fused<6>(ctx, p, grid); break;
+    case 7: rc = launch_fused<7>(ctx, p, grid); break;
+    default: rc = launch_fused<8>(ctx, p, grid); break;
   }
   if (rc != RT_OK) return rc;
   if (ctx->profile) {
