@@ -187,14 +187,15 @@ __device__ __forceinline__ void project_wave(const ProjParams& p, double* sm) {
   for (int q = 0; q < (N1 > 0 ? N1 : 1); ++q) acc1[q] = d4{0.0, 0.0, 0.0, 0.0};
 
   // per-thread constants of the window copy: pair q of the thread sits at row w_row[q], columns 2 cp, 2 cp + 1
-  int w_goff[NW], w_loff[NW], w_row[NW];
+  unsigned w_goff[NW];
+  int w_loff[NW], w_row[NW];
   bool w_c0[NW], w_c1[NW];
 #pragma unroll
   for (int q = 0; q < NW; ++q) {
     const int pidx = tid + PT * q;
     const int row = pidx / PAIRS, cp = pidx % PAIRS;
     w_row[q] = (row < WROWS) ? row : (1 << 20);   // never < nrow
-    w_goff[q] = row * (int)p.ldv + 2 * cp;
+    w_goff[q] = (row * (int)p.ldv + 2 * cp) * 8;  // bytes
     w_loff[q] = row * STRIDE + 2 * cp;
     w_c0[q] = 2 * cp < r;
     w_c1[q] = 2 * cp + 1 < r;
@@ -207,34 +208,37 @@ __device__ __forceinline__ void project_wave(const ProjParams& p, double* sm) {
   int creg = 0, nb_lo = 0, nb_hi = 0;
   StageRec rn{};
 
+  // every global address below is (wave-uniform base) + (32-bit per-thread offset): the loads use the
+  // scalar-base addressing mode and need no 64-bit VALU arithmetic
+  const unsigned ent_off = (unsigned)tid * (unsigned)p.d_es * 8u, idx_off = (unsigned)tid * 8u, row_off = (unsigned)kk * 8u;
+  auto ld = [](const void* base, unsigned off) { return *reinterpret_cast<const double*>(static_cast<const char*>(base) + off); };
+  auto ldi = [](const void* base, unsigned off) { return (int)*reinterpret_cast<const long*>(static_cast<const char*>(base) + off); };
   auto fetch = [&](long k0, const StageRec& rc) {  // issue the loads of stage k0 (no LDS access, no dependent load)
     rn = rc;
-    const long k1 = (k0 + PK < kend) ? k0 + PK : kend;
-    const int nrow = (rc.hi >= 0) ? (rc.hi - rc.lo + 1) : (int)(k1 - k0);
+    const int rows_left = (int)((kend - k0 < PK) ? kend - k0 : PK);
+    const int nrow = (rc.hi >= 0) ? (rc.hi - rc.lo + 1) : rows_left;
     const double* vbase = p.V + (long)rc.lo * p.ldv;  // wave-uniform
 #pragma unroll
     for (int q = 0; q < NW; ++q) {
       d2 v{0.0, 0.0};
       if (w_row[q] < nrow) {
-        const double* src = vbase + w_goff[q];
+        const char* src = reinterpret_cast<const char*>(vbase) + w_goff[q];
         if (vec2 && w_c1[q]) {
           v = *reinterpret_cast<const d2*>(src);
         } else {
-          if (w_c0[q]) v.x = src[0];
-          if (w_c1[q]) v.y = src[1];
+          if (w_c0[q]) v.x = *reinterpret_cast<const double*>(src);
+          if (w_c1[q]) v.y = *reinterpret_cast<const double*>(src + 8);
         }
       }
       wreg[q] = v;
     }
     if (rc.hi >= 0) {
-      const long e = rc.e0 + tid;
-      const bool v = e < rc.e1;
-      vreg = v ? dat[e * p.d_es] : 0.0;
-      creg = v ? (int)p.indices[e] - rc.lo : 0;
-      const long kr = k0 + kk;  // entry range of this thread's row, low words (a stage holds < 2^31 entries)
-      const bool rv = kr < kend;
-      nb_lo = rv ? (int)p.indptr[kr] : 0;
-      nb_hi = rv ? (int)p.indptr[kr + 1] : 0;
+      const bool v = tid < (int)(rc.e1 - rc.e0);
+      vreg = v ? ld(dat + rc.e0 * p.d_es, ent_off) : 0.0;
+      creg = v ? ldi(p.indices + rc.e0, idx_off) - rc.lo : 0;
+      const bool rv = kk < rows_left;  // entry range of this thread's row, low words (a stage holds < 2^31 entries)
+      nb_lo = rv ? ldi(p.indptr + k0, row_off) : 0;
+      nb_hi = rv ? ldi(p.indptr + k0 + 1, row_off) : 0;
     }
   };
   int c_lo = 0, c_hi = -1, row_base = 0, row_cnt = 0;
@@ -382,7 +386,8 @@ int rt_project_fused(rt_ctx* ctx, const int64_t* indptr, const int64_t* indices,
                      int64_t d_bs, int64_t B, int64_t N, const double* V, int64_t ldv, int64_t r, double* AN,
                      const void* stage_table) {
   if (r > RMAX) return RT_ERR_UNSUPPORTED;
-  if ((int64_t)WROWS * ldv + RMAX >= (1LL << 31)) return RT_ERR_UNSUPPORTED;  // 32-bit window offsets
+  if (((int64_t)WROWS * ldv + RMAX) * 8 >= (1LL << 31) || d_es * 8 * EMAX >= (1LL << 31))
+    return RT_ERR_UNSUPPORTED;  // 32-bit per-thread byte offsets
   ProjParams p;
   p.indptr = reinterpret_cast<const long*>(indptr);
   p.indices = reinterpret_cast<const long*>(indices);
