@@ -35,7 +35,7 @@ def _stale(target, deps):
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_panel.h"), os.path.join(HERE, "..", "include", "romtime_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_panel.h"), os.path.join(CSRC, "wave_ops.h"), os.path.join(HERE, "..", "include", "romtime_hip.h")]
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)

@@ -18,12 +18,14 @@
 // The caller (pod.py) finishes with a k x k Rayleigh-Ritz step on G, which also repairs clustered
 // eigenvalues, and checks the residual; any failure falls back to... nothing silent: it raises.
 #include "common.h"
+#include "wave_ops.h"
 
 namespace {
 
 constexpr int TW = 32;      // workgroups of the tridiagonalisation
 constexpr int LPR = 64;     // lanes per matrix row in the mat-vec / rank-2 update (TT / LPR rows per pass)
 constexpr int TT = 1024;    // threads per workgroup
+static_assert(LPR == 64, "row reductions use the whole-wave DPP sum");
 constexpr int NMAX = 512;
 
 struct TriParams {
@@ -65,8 +67,7 @@ __device__ __forceinline__ bool wait_flag(int* flag, int want, int* err, int* s_
 }
 
 __device__ __forceinline__ double block_sum(double x, double* s_red) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off);
+  x = rtw::wave_sum(x);
   const int wid = threadIdx.x >> 6;
   __syncthreads();
   if ((threadIdx.x & 63) == 0) s_red[wid] = x;
@@ -126,9 +127,8 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
         v[q] = (j < n) ? sl[j] : 0.0;
         if (!(lane == 0 && q == 0)) part = fma(v[q], v[q], part);
       }
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
-      const double alpha = __shfl(v[0], 0);
+      part = rtw::wave_sum(part);
+      const double alpha = rtw::first_lane(v[0]);
       double tau, beta, scale;
       if (part == 0.0) {
         tau = 0.0; beta = alpha; scale = 0.0;
@@ -168,8 +168,7 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
         if (tau != 0.0) {
           double acc = 0.0;
           for (int j = k + 1 + tx; j < n; j += LPR) acc = fma(row[j], sv[j], acc);
-#pragma unroll
-          for (int off = LPR / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+          acc = rtw::wave_sum(acc);
           if (tx == 0) st_wt(&Pk[gi], tau * acc);
         }
         if (gi == k + 1)
@@ -196,12 +195,11 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
         double dot = 0.0;
 #pragma unroll
         for (int q = 0; q < PER; ++q) dot = fma(pv[q], v[q], dot);
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+        dot = rtw::wave_sum(dot);
         const double alpha2 = -0.5 * tau * dot;
 #pragma unroll
         for (int q = 0; q < PER; ++q) pv[q] = fma(alpha2, v[q], pv[q]);  // pv now holds w
-        const double w1 = __shfl(pv[0], 0);                              // w_{k+1}; v_{k+1} = 1
+        const double w1 = rtw::first_lane(pv[0]);                        // w_{k+1}; v_{k+1} = 1
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
           const int j = k + 1 + lane + 64 * q;
