@@ -117,7 +117,7 @@ int rt_project_csr_batched(rt_ctx* ctx, const int64_t* indptr, const int64_t* in
 /* ---- reduced solve (np.linalg.solve: deim.py:491-492; gmres on a dense r x r: rom.py:492) --- */
 
 /* Solve K_b x_b = rhs_b for b < B by LU with partial pivoting, one workgroup per system.
- * K (B x r x r row-major) is overwritten with its factors, rhs (B x r) with x.
+ * K (B x r x r row-major) is left untouched (the factors are not an output), rhs (B x r) is overwritten with x.
  * info (B device ints, may be NULL): 0, or RT_WARN_SINGULAR. r <= 128. */
 int rt_dense_solve_batched(rt_ctx* ctx, double* K, double* rhs, int64_t r, int64_t B, int* info);
 

@@ -40,4 +40,56 @@ __device__ __forceinline__ double wave_sum(double x) {
   return read_lane(x, 63);
 }
 
+// Variants whose masked-off lanes keep their own value (op(x, x) == x): for min / max / argmax.
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ int dpp_keep_i32(int x) {
+  return __builtin_amdgcn_update_dpp(x, x, CTRL, ROW_MASK, BANK_MASK, false);
+}
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ double dpp_keep_f64(double x) {
+  const long long b = __double_as_longlong(x);
+  const int lo = dpp_keep_i32<CTRL, ROW_MASK, BANK_MASK>((int)b), hi = dpp_keep_i32<CTRL, ROW_MASK, BANK_MASK>((int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned)lo);
+}
+
+__device__ __forceinline__ double wave_max(double x) {
+  x = fmax(x, dpp_keep_f64<0xb1>(x));
+  x = fmax(x, dpp_keep_f64<0x4e>(x));
+  x = fmax(x, dpp_keep_f64<0x114>(x));
+  x = fmax(x, dpp_keep_f64<0x118>(x));
+  x = fmax(x, dpp_keep_f64<0x142, 0xa>(x));
+  x = fmax(x, dpp_keep_f64<0x143, 0xc>(x));
+  return read_lane(x, 63);
+}
+
+__device__ __forceinline__ double wave_min(double x) {
+  x = fmin(x, dpp_keep_f64<0xb1>(x));
+  x = fmin(x, dpp_keep_f64<0x4e>(x));
+  x = fmin(x, dpp_keep_f64<0x114>(x));
+  x = fmin(x, dpp_keep_f64<0x118>(x));
+  x = fmin(x, dpp_keep_f64<0x142, 0xa>(x));
+  x = fmin(x, dpp_keep_f64<0x143, 0xc>(x));
+  return read_lane(x, 63);
+}
+
+// argmax over the wave with the order (value descending, index ascending); wave-uniform result
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ void argmax_step(double& v, int& i) {
+  const double ov = dpp_keep_f64<CTRL, ROW_MASK, BANK_MASK>(v);
+  const int oi = dpp_keep_i32<CTRL, ROW_MASK, BANK_MASK>(i);
+  const bool take = ov > v || (ov == v && oi < i);
+  v = take ? ov : v;
+  i = take ? oi : i;
+}
+__device__ __forceinline__ void wave_argmax(double& v, int& i) {
+  argmax_step<0xb1>(v, i);
+  argmax_step<0x4e>(v, i);
+  argmax_step<0x114>(v, i);
+  argmax_step<0x118>(v, i);
+  argmax_step<0x142, 0xa>(v, i);
+  argmax_step<0x143, 0xc>(v, i);
+  v = read_lane(v, 63);
+  i = __builtin_amdgcn_readlane(i, 63);
+}
+
 }  // namespace rtw
