@@ -55,6 +55,11 @@ int rt_gemm_strided(rt_ctx* ctx, const double* A, int64_t a_ks, int64_t a_ms, co
 // Specialised Gram kernel (gram_mfma.hip); RT_ERR_UNSUPPORTED means "use rt_gemm_strided".
 int rt_gram128(rt_ctx* ctx, const double* X, int64_t ks, int64_t ms, int64_t K, int64_t n, double* G);
 
+// Newton-Schulz inverse tracking solve for the online sweep (solve.hip); RT_ERR_UNSUPPORTED for r > 80.
+int rt_newton_solve_batched(rt_ctx* ctx, const double* K, double* Xinv, double* rhs, int64_t r, int64_t B,
+                            int have_prev, int* info);
+int rt_dense_solve_batched_if(rt_ctx* ctx, double* K, double* rhs, int64_t r, int64_t B, int* info, const int* only_if);
+
 // Fused SpMM + V^T(.) projection (project_fused.hip); RT_ERR_UNSUPPORTED for r > 128.  `stage_table` is the
 // per-pattern table built by rt_project_stage_table (rt_project_stage_table_bytes(N) bytes of device memory), or
 // nullptr to have it built on every call.

@@ -16,6 +16,8 @@
 #include "common.h"
 #include "wave_ops.h"
 
+typedef double d4 __attribute__((ext_vector_type(4)));
+
 namespace {
 
 constexpr int SOLVE_THREADS = 256;
@@ -24,7 +26,8 @@ constexpr int SOLVE_BATCH = 4;
 
 __global__ __launch_bounds__(SOLVE_THREADS) void dense_solve_kernel(const double* __restrict__ K,
                                                                     double* __restrict__ rhs, int r, int parts,
-                                                                    int* __restrict__ info) {
+                                                                    int* info, const int* only_if) {
+  if (only_if && only_if[blockIdx.x] == 0) return;  // fallback launch: only the systems another solver gave up on
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int lda = r | 1;  // odd leading dimension: column walks hit distinct banks
   double* A = sm;         // r x lda
@@ -122,9 +125,197 @@ __global__ __launch_bounds__(SOLVE_THREADS) void dense_solve_kernel(const double
   if (info && tid == 0) info[blockIdx.x] = sing ? RT_WARN_SINGULAR : 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Inverse tracking for the online sweep.  Consecutive time steps solve with matrices that differ by O(dt), and
+// pivoted LU of an 80 x 80 system is a chain of ~80 x 3500 dependent cycles no matter how many threads help.
+// Newton-Schulz  X <- X (2 I - K X)  converges quadratically to K^-1 from the previous step's inverse
+// (||I - K X|| ~ 1e-4 -> 1e-8 -> 1e-16) and is two small GEMMs on the matrix cores per iteration, all operands
+// resident in LDS.  One workgroup per system: iterate until the residual before the last update was < 1e-6
+// (so < 1e-12 after it), then x = X b with one step of iterative refinement against K itself, which makes the
+// answer as accurate as the direct solve.  Without a usable start (first step, or ||I - K X|| > 0.7) it
+// restarts from X = K^T / (||K||_1 ||K||_inf), which always converges for a nonsingular K.
+constexpr int NS_THREADS = 512;
+constexpr int NS_MAX_ITER = 100;
+
+__device__ __forceinline__ double ns_block_sum(double x, double* s_red, int tid) {
+  x = rtw::wave_sum(x);
+  __syncthreads();
+  if ((tid & 63) == 0) s_red[tid >> 6] = x;
+  __syncthreads();
+  double t = 0.0;
+#pragma unroll
+  for (int w = 0; w < NS_THREADS / 64; ++w) t += s_red[w];
+  return t;
+}
+
+__device__ __forceinline__ double ns_block_max(double x, double* s_red, int tid) {
+  x = rtw::wave_max(x);
+  __syncthreads();
+  if ((tid & 63) == 0) s_red[tid >> 6] = x;
+  __syncthreads();
+  double t = s_red[0];
+#pragma unroll
+  for (int w = 1; w < NS_THREADS / 64; ++w) t = fmax(t, s_red[w]);
+  return t;
+}
+
+__global__ __launch_bounds__(NS_THREADS) void newton_solve_kernel(const double* __restrict__ K,
+                                                                  double* __restrict__ Xinv,
+                                                                  double* __restrict__ rhs, int r, int S,
+                                                                  int have_prev, int* __restrict__ info) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int tr = (r + 15) / 16, rp = tr * 16, ntile = tr * tr;
+  double* sK = sm;                    // [rp][S], padded with the identity
+  double* sX = sK + (size_t)rp * S;   // [rp][S]
+  double* sT = sX + (size_t)rp * S;   // [rp][S]
+  __shared__ double s_red[NS_THREADS / 64];
+  __shared__ double s_vec[3][128];
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const double* Kb = K + (size_t)blockIdx.x * r * r;
+  double* Xb = Xinv + (size_t)blockIdx.x * r * r;
+  double* rb = rhs + (size_t)blockIdx.x * r;
+
+  for (int i = wid; i < rp; i += NS_THREADS / 64)
+    for (int j = lane; j < rp; j += 64) {
+      const bool in = i < r && j < r;
+      const double eye = (i == j) ? 1.0 : 0.0;
+      sK[i * S + j] = in ? Kb[i * r + j] : eye;
+      sX[i * S + j] = (in && have_prev) ? Xb[i * r + j] : eye;
+    }
+  if (tid < r) s_vec[0][tid] = rb[tid];
+  __syncthreads();
+
+  // C(ti, tj) = sum_k A[16 ti + i][k] B[k][16 tj + j]; tile t = wid + 8 q belongs to this wave (q < 4 as r <= 80)
+  constexpr int NSQ = 4;
+  auto tiles_product = [&](const double* A, const double* Bm, d4 (&acc)[NSQ]) {
+    const double* a[NSQ];
+    const double* bq[NSQ];
+#pragma unroll
+    for (int q = 0; q < NSQ; ++q) {
+      const int t = (wid + 8 * q < ntile) ? wid + 8 * q : 0;
+      const int ti = t / tr, tj = t - ti * tr;
+      a[q] = A + (16 * ti + l15) * S + l4;
+      bq[q] = Bm + l4 * S + 16 * tj + l15;
+      acc[q] = d4{0.0, 0.0, 0.0, 0.0};
+    }
+    for (int k4 = 0; k4 < rp / 4; ++k4) {
+#pragma unroll
+      for (int q = 0; q < NSQ; ++q)
+        if (wid + 8 * q < ntile)  // wave-uniform
+          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][4 * k4], bq[q][4 * k4 * S], acc[q], 0, 0, 0);
+    }
+  };
+
+  auto restart = [&]() {  // X = K^T / (||K||_1 ||K||_inf)
+    double rs = 0.0, cs = 0.0;
+    if (tid < r) {
+      for (int j = 0; j < r; ++j) {
+        rs += fabs(sK[tid * S + j]);
+        cs += fabs(sK[j * S + tid]);
+      }
+    }
+    const double ninf = ns_block_max(rs, s_red, tid);
+    const double n1 = ns_block_max(cs, s_red, tid);
+    const double sc = 1.0 / (n1 * ninf);
+    for (int i = wid; i < rp; i += NS_THREADS / 64)
+      for (int j = lane; j < rp; j += 64) sX[i * S + j] = (i < r && j < r) ? sK[j * S + i] * sc : ((i == j) ? 1.0 : 0.0);
+    __syncthreads();
+  };
+  if (!have_prev) restart();
+
+  int status = RT_WARN_SINGULAR;
+  bool restarted = !have_prev;
+  for (int it = 0; it < NS_MAX_ITER; ++it) {
+    // T = K X and the residual ||I - T||_F
+    double part = 0.0;
+    d4 acc[NSQ];
+    tiles_product(sK, sX, acc);
+#pragma unroll
+    for (int q = 0; q < NSQ; ++q) {
+      const int t = wid + 8 * q;
+      if (t < ntile) {
+        const int ti = t / tr, tj = t - ti * tr;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int row = 16 * ti + l4 + 4 * c, col = 16 * tj + l15;
+          sT[row * S + col] = acc[q][c];
+          const double e = ((row == col) ? 1.0 : 0.0) - acc[q][c];
+          part = fma(e, e, part);
+        }
+      }
+    }
+    const double res = sqrt(ns_block_sum(part, s_red, tid));  // barriers inside: sT complete
+    if (res != res) break;  // NaN: singular to working precision (or bad input)
+    if (!restarted && !(res < 0.7)) {  // the carried inverse is no contraction for this K: safe start instead
+      restarted = true;
+      restart();
+      continue;
+    }
+    // X <- 2 X - X T
+    tiles_product(sX, sT, acc);
+    __syncthreads();  // every wave has finished reading the old X
+#pragma unroll
+    for (int q = 0; q < NSQ; ++q) {
+      const int t = wid + 8 * q;
+      if (t < ntile) {
+        const int ti = t / tr, tj = t - ti * tr;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int row = 16 * ti + l4 + 4 * c, col = 16 * tj + l15;
+          sX[row * S + col] = 2.0 * sX[row * S + col] - acc[q][c];
+        }
+      }
+    }
+    __syncthreads();
+    if (res < 1e-6) {
+      status = 0;
+      break;
+    }
+  }
+
+  if (status != 0) {  // leave rhs for the LU fallback and make the next call start afresh
+    for (int i = wid; i < r; i += NS_THREADS / 64)
+      for (int j = lane; j < r; j += 64) Xb[i * r + j] = 0.0;
+    if (info && tid == 0) info[blockIdx.x] = status;
+    return;
+  }
+  // x = X b, one refinement step against K:  x += X (b - K x)
+  double x = 0.0;
+  if (tid < r) {
+    for (int j = 0; j < r; ++j) x = fma(sX[tid * S + j], s_vec[0][j], x);
+    s_vec[1][tid] = x;
+  }
+  __syncthreads();
+  if (tid < r) {
+    double rr = s_vec[0][tid];
+    for (int j = 0; j < r; ++j) rr = fma(-sK[tid * S + j], s_vec[1][j], rr);
+    s_vec[2][tid] = rr;
+  }
+  __syncthreads();
+  if (tid < r) {
+    for (int j = 0; j < r; ++j) x = fma(sX[tid * S + j], s_vec[2][j], x);
+    rb[tid] = x;
+  }
+  for (int i = wid; i < r; i += NS_THREADS / 64)
+    for (int j = lane; j < r; j += 64) Xb[i * r + j] = sX[i * S + j];
+  if (info && tid == 0) info[blockIdx.x] = status;
+}
+
 }  // namespace
 
+static int dense_solve_launch(rt_ctx* ctx, double* K, double* rhs, int64_t r, int64_t B, int* info, const int* only_if);
+
 extern "C" int rt_dense_solve_batched(rt_ctx* ctx, double* K, double* rhs, int64_t r, int64_t B, int* info) {
+  return dense_solve_launch(ctx, K, rhs, r, B, info, nullptr);
+}
+
+// Internal (sweep.hip): the LU solve for the systems b with only_if[b] != 0 (a device array, no host sync).
+int rt_dense_solve_batched_if(rt_ctx* ctx, double* K, double* rhs, int64_t r, int64_t B, int* info, const int* only_if) {
+  return dense_solve_launch(ctx, K, rhs, r, B, info, only_if);
+}
+
+static int dense_solve_launch(rt_ctx* ctx, double* K, double* rhs, int64_t r, int64_t B, int* info, const int* only_if) {
   if (!ctx) return RT_ERR_ARG;
   RT_ARG_CHECK(ctx, K && rhs && r >= 1 && B >= 1);
   if (r > 128) {
@@ -142,7 +333,29 @@ extern "C" int rt_dense_solve_batched(rt_ctx* ctx, double* K, double* rhs, int64
   int parts = SOLVE_THREADS / (int)r;  // threads per row
   if (parts > 8) parts = 8;
   hipLaunchKernelGGL(dense_solve_kernel, dim3((unsigned)B), dim3(SOLVE_THREADS), lds, ctx->stream, K, rhs, (int)r,
-                     parts, info);
+                     parts, info, only_if);
+  RT_HIP_CHECK(ctx, hipGetLastError());
+  return RT_OK;
+}
+
+// Internal (sweep.hip): solve K_b x_b = rhs_b while tracking K_b^-1 in Xinv (B x r x r, caller-owned, carried
+// from call to call).  have_prev = 0 on the first call.  RT_ERR_UNSUPPORTED when three padded r x r matrices
+// do not fit the LDS (r > 80): the caller uses rt_dense_solve_batched.
+int rt_newton_solve_batched(rt_ctx* ctx, const double* K, double* Xinv, double* rhs, int64_t r, int64_t B,
+                            int have_prev, int* info) {
+  const int rp = (int)((r + 15) / 16) * 16;
+  int S = rp;
+  while (S % 4 != 2) ++S;  // 2 S == 4 (mod 8): the 16 rows of an A-operand read fall in distinct LDS banks
+  const size_t lds = sizeof(double) * 3 * (size_t)rp * S;
+  if (lds > 156 * 1024) return RT_ERR_UNSUPPORTED;  // + 3 KB of static LDS = the CU's 160 KB
+  static bool attr_set = false;
+  if (!attr_set) {
+    RT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&newton_solve_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(newton_solve_kernel, dim3((unsigned)B), dim3(NS_THREADS), lds, ctx->stream, K, Xinv, rhs, (int)r, S,
+                     have_prev, info);
   RT_HIP_CHECK(ctx, hipGetLastError());
   return RT_OK;
 }

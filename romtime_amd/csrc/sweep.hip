@@ -87,7 +87,8 @@ extern "C" int rt_rom_bdf_sweep(rt_ctx* ctx, const rt_sweep_desc* d, double* uN_
                oKN = take(sizeof(double) * B * r * r), oRhs = take(sizeof(double) * B * r), oUn = take(sizeof(double) * B * r),
                oUm = take(sizeof(double) * B * r), oUh = take(sizeof(double) * B * N), oUp = take(sizeof(double) * B * N),
                oXT = take(sizeof(double) * r * B), oInfo = take(sizeof(int) * B),
-               oKv = take(sizeof(double) * B * nnz), oTab = take(rt_project_stage_table_bytes(N));
+               oKv = take(sizeof(double) * B * nnz), oTab = take(rt_project_stage_table_bytes(N)),
+               oXi = take(sizeof(double) * B * r * r);
   void* base = nullptr;
   int rc = rt_scratch2(ctx, off, &base);
   if (rc != RT_OK) return rc;
@@ -104,6 +105,7 @@ extern "C" int rt_rom_bdf_sweep(rt_ctx* ctx, const rt_sweep_desc* d, double* uN_
   double* xT = reinterpret_cast<double*>(b8 + oXT);
   int* info = reinterpret_cast<int*>(b8 + oInfo);
   double* kval = reinterpret_cast<double*>(b8 + oKv);
+  double* Xinv = reinterpret_cast<double*>(b8 + oXi);  // K_N^-1 of the previous step, per parameter point
   void* stage_table = b8 + oTab;  // per-pattern stage records of the fused projection, built once per sweep
 
   RT_HIP_CHECK(ctx, hipMemsetAsync(un, 0, sizeof(double) * B * r, st));
@@ -138,7 +140,13 @@ extern "C" int rt_rom_bdf_sweep(rt_ctx* ctx, const rt_sweep_desc* d, double* uN_
     hipLaunchKernelGGL(sweep_rhs_kernel, dim3((unsigned)B), dim3(128), sizeof(double) * r, st, MN, un, unm1, c0, c1,
                        d->dt, F ? d->rhs_coef + step * B * F : nullptr, fN, F, (int)r, rhs);
     RT_HIP_CHECK(ctx, hipGetLastError());
-    rc = rt_dense_solve_batched(ctx, KN, rhs, r, B, info);
+    // consecutive K_N differ by O(dt): refresh the tracked inverse on the matrix cores; LU only for the systems
+    // where that fails (decided on the device) or when r is too large for the LDS-resident iteration
+    rc = rt_newton_solve_batched(ctx, KN, Xinv, rhs, r, B, step > 0 ? 1 : 0, info);
+    if (rc == RT_OK)
+      rc = rt_dense_solve_batched_if(ctx, KN, rhs, r, B, info, info);
+    else if (rc == RT_ERR_UNSUPPORTED)
+      rc = rt_dense_solve_batched(ctx, KN, rhs, r, B, info);
     if (rc != RT_OK) return rc;
     hipLaunchKernelGGL(sweep_store_kernel, dim3((unsigned)B), dim3(128), 0, st, rhs, un, unm1, uN_out, step, nt, (int)r,
                        d->bdf2 ? 1 : 0);
