@@ -101,14 +101,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: romtime_amd has no CPU path")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # ROMTIME_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks then share
+    # devices; RCCL refuses that).  The driver's runs use the default: nccl (= RCCL), one rank per GPU.
+    backend = os.environ.get("ROMTIME_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     group = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
         group = dist.group.WORLD
 
     from romtime_amd import pod

@@ -104,7 +104,9 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
   int hop = 0;                                // counter target is hop * TW
 
   // step "-1": row 0 to everybody
-  double* L0 = p.P + (size_t)2 * n;           // P = [p even | p odd | row even | row odd]
+  // P = [p even | p odd | row even | row odd].  Row 0 travels in the ODD row buffer: step 0 stores into the even
+  // one, and a workgroup may get there before a slow one has read row 0.
+  double* L0 = p.P + (size_t)3 * n;
   if (wg == 0)
     for (int j = tid; j < n; j += TT) st_wt(&L0[j], A[j]);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
