@@ -266,6 +266,45 @@ def check_to_rom_roundtrip():
     assert rom.N == 9 and rom.shape == V.shape
 
 
+def check_artefact_round_trip(golden_deim, tmp_path, monkeypatch):
+    """On-disk artefacts keep the reference's names and payloads (deim.py:77-81,166-173; conventions.py:4-12;
+    hrom.py:151-166): a basis dumped by one reductor is adopted by a fresh one under the same name, and the
+    ROM basis / parameter-space files use the StorageNames strings."""
+    import json
+    import pickle
+
+    from romtime_amd.conventions import StorageNames
+    from romtime_amd.deim import DiscreteEmpiricalInterpolation
+    from romtime_amd.mdeim import MatrixDiscreteEmpiricalInterpolation
+    from romtime_amd.utils import dump_pickle, read_pickle
+
+    monkeypatch.chdir(tmp_path)
+    assert (StorageNames.ROM, StorageNames.SROM, StorageNames.MU_SPACE, StorageNames.MU_SPACE_DEIM) == (
+        "basis_rom.pkl", "basis_srom.pkl", "mu_space.json", "mu_space_deim.json")
+    g = golden_deim
+    basis = g["basis__random_orth_300x16"].copy()
+    d = DiscreteEmpiricalInterpolation(assemble=None, name="RHS  Forcing")
+    assert d.basis_pickle_name == "basis_fom_deim_rhs_forcing.pkl"
+    md = MatrixDiscreteEmpiricalInterpolation(assemble=None, name="Mass")
+    assert md.basis_pickle_name == "basis_fom_mdeim_mass.pkl"
+    d.load_fom_basis(basis=basis)
+    d.dump_fom_basis()
+    with open("basis_fom_deim_rhs_forcing.pkl", "rb") as fp:   # a plain pickled ndarray, as the reference writes
+        raw = pickle.load(fp)
+    assert isinstance(raw, np.ndarray) and np.array_equal(raw, basis)
+    d2 = DiscreteEmpiricalInterpolation(assemble=None, name="rhs forcing")
+    d2.load_fom_basis(keep=12)                                   # from disk, truncated (hrom.py:389)
+    assert d2.N == 12 and np.array_equal(d2.basis_fom, basis[:, :12])
+    assert list(d2.dofs) == list(d.dofs)[:12]                    # greedy is nested in the leading columns
+    rows = [t[0] for t in d2.dofs]                               # store_dofs keeps (dof,) tuples (deim.py:217-224)
+    assert_allclose(d2.PT_U, basis[rows, :12], rtol=0, atol=0)
+    dump_pickle(StorageNames.ROM, basis)
+    assert np.array_equal(read_pickle(StorageNames.ROM), basis)
+    with open(StorageNames.MU_SPACE, "w") as fp:
+        json.dump({"offline": [dict(alpha=1.0)], "online": [], "validation": []}, fp)
+    assert json.load(open(StorageNames.MU_SPACE))["offline"][0]["alpha"] == 1.0
+
+
 # ----------------------------------------------------------------------------------------------
 # host-logic runs (device operators stubbed) ---------------------------------------------------
 def test_orth_golden_hostlogic(cpu_ops, golden_orth):
@@ -300,6 +339,10 @@ def test_rom_offline_hostlogic(cpu_ops):
 
 def test_to_rom_hostlogic(cpu_ops):
     check_to_rom_roundtrip()
+
+
+def test_artefact_round_trip_hostlogic(cpu_ops, golden_deim, tmp_path, monkeypatch):
+    check_artefact_round_trip(golden_deim, tmp_path, monkeypatch)
 
 
 def test_product_path_fails_loudly_without_gpu():
