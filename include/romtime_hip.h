@@ -143,6 +143,32 @@ typedef struct {
  * (rom.py:451-453).  uN_out: n_mu x nt x r (device).  Everything stays on the ctx stream. */
 int rt_rom_bdf_sweep(rt_ctx* ctx, const rt_sweep_desc* desc, double* uN_out);
 
+/* ---- hyper-reduced online sweep (the (M)DEIM path of RomConstructor*.solve: interpolate(which=ROM),
+ *      deim.py:416-452,477-493, mdeim.py:230-261; assemble_system rom.py:877-929) on the device ------------- */
+typedef struct {
+  int64_t r, n_mu, nt;           /* reduced size (<= 128), parameter points, time steps */
+  double dt;
+  int bdf2;                      /* as rt_sweep_desc */
+  int64_t m_mass, m_lin, m_nl, m_rhs; /* interpolation coefficients: mass operator, the other (mu,t)-dependent
+                                    operators together, the state-dependent operator, the source vectors */
+  const double* Z;               /* (m_mass + m_lin + m_nl) x (r*r): row e = the r x r matrix that local entry e
+                                    multiplies = column e of basis_rom PT_U^-1 (mdeim.py:153-192 with the theta
+                                    solve of deim.py:491-492 folded in); blocks in the order mass | lin | nl */
+  const double* Zf;              /* m_rhs x r: the same for the DEIM source vectors (deim.py:495-515) */
+  const double* F_mass;          /* nt x n_mu x m_mass: the operator's entries at its interpolation entries,
+                                    assemble(mu, t, entries=dofs) (deim.py:429-433), for every step and mu */
+  const double* F_lin;           /* nt x n_mu x m_lin */
+  const double* F_rhs;           /* nt x n_mu x m_rhs */
+  const double* W;               /* m_nl x r: local entries of the state-dependent operator are S (W u_N* + C)
+                                    (N-MDEIM, nonlinear.py:247-283: the trilinear form is linear in u_h = V u_N) */
+  const double* C_nl;            /* nt x n_mu x m_nl or NULL */
+  const double* S_nl;            /* nt x n_mu or NULL (= 1) */
+} rt_hsweep_desc;
+/* M_N = sum_e F_mass[e] Z_e;  K_N = bdf M_N + dt (sum_e F_lin[e] Z_e + sum_e S (W u* + C)_e Z_e);
+ * b_N = M_N (2u^n - u^{n-1}/2) + dt Zf^T F_rhs;  u* = 2u^n - u^{n-1} (BDF2) or u^n;  zero initial condition.
+ * No quantity of size N_h is touched.  uN_out: n_mu x nt x r (device). */
+int rt_hrom_bdf_sweep(rt_ctx* ctx, const rt_hsweep_desc* desc, double* uN_out);
+
 /* ---- small symmetric eigenproblem of the Gram matrix, on the device (3 <= n <= 512) ----------- */
 /* Householder tridiagonalisation (16 workgroups, matrix resident in LDS) + Sturm multisection:
  * lam (n, device) = all eigenvalues of the symmetric G (n x n row-major, not modified), DESCENDING.

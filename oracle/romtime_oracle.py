@@ -258,3 +258,54 @@ def rom_solve_nonlinear(fom, V, mu, solver=reduced_solve):
         uN_n = uN.copy()
         fom_coeffs.append(uh + fom.lifting(mu, t))
     return np.vstack(rom_coeffs).T, np.vstack(fom_coeffs).T
+
+
+def _interp_rom(term, f_local):
+    """``interpolate(which=ROM)``: theta = solve(PT_U, f_local) (deim.py:491-492, a fresh dgesv per call),
+    approx = sum_i theta_i basis_rom[:, i] (deim.py:445); an MDEIM reshapes to (N_V, N_V) (mdeim.py:252-259)."""
+    theta = compute_thetas(term["PT_U"], f_local)
+    approx = term["basis_rom"].dot(theta)
+    n = term["basis_rom"].shape[0]
+    r = int(round(np.sqrt(n)))
+    return approx.reshape(r, r) if r * r == n and term.get("matrix", True) else approx
+
+
+def hrom_solve(mass, lin, nl, rhs, b, r, nt, dt, bdf2, solver=np.linalg.solve):
+    """Online loop of RomConstructorNonlinear.solve (rom.py:430-555) with every operator hyper-reduced, for the
+    parameter point with index ``b`` of the tables.
+
+    mass: one term; lin: list of terms (stiffness, convection, nonlinear lifting ...); rhs: list of vector
+    terms (``matrix=False``); each term = dict(PT_U (m x m), basis_rom (r^2 x m | r x m), F (nt x n_mu x m) = the
+    operator's entries at its interpolation entries, assemble(mu, t, entries=dofs), deim.py:429-433).
+    nl: None or dict(PT_U, basis_rom, W (m x r), C (nt x n_mu x m) | None, S (nt x n_mu) | None): the entries of
+    the state-dependent operator are S (W u_N* + C) (N-MDEIM, nonlinear.py:247-283).  K_N / b_N as
+    assemble_system / assemble_system_rhs (rom.py:877-929, 714-736).  Returns the r x nt trajectory."""
+    uN_n = np.zeros(r)
+    uN_n1 = np.zeros(r) if bdf2 else None
+    first = True
+    out = []
+    for step in range(nt):
+        bdf = 1.5 if (bdf2 and step > 0) else 1.0
+        MN = _interp_rom(mass, mass["F"][step, b])
+        KN = bdf * MN
+        for term in lin:
+            KN = KN + dt * _interp_rom(term, term["F"][step, b])
+        if nl is not None:
+            u_star = uN_n if (uN_n1 is None or first) else 2.0 * uN_n - uN_n1
+            f_local = nl["W"].dot(u_star)
+            if nl.get("C") is not None:
+                f_local = f_local + nl["C"][step, b]
+            if nl.get("S") is not None:
+                f_local = nl["S"][step, b] * f_local
+            KN = KN + dt * _interp_rom(nl, f_local)
+        fN = np.zeros(r)
+        for term in rhs:
+            fN = fN + _interp_rom(dict(term, matrix=False), term["F"][step, b])
+        bN = assemble_system_rhs(MN, fN, uN_n, uN_n1, dt)
+        uN = solver(KN, bN)
+        out.append(uN)
+        if bdf2:
+            uN_n1 = uN_n.copy()
+        uN_n = uN.copy()
+        first = False
+    return np.vstack(out).T

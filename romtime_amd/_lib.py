@@ -43,6 +43,7 @@ SIGNATURES = {
     "rt_project_csr_batched": (_int, [_p, _p, _p, _p, _i64, _int, _i64, _i64, _p, _i64, _i64, _p]),
     "rt_dense_solve_batched": (_int, [_p, _p, _p, _i64, _i64, _p]),
     "rt_rom_bdf_sweep": (_int, [_p, _p, _p]),
+    "rt_hrom_bdf_sweep": (_int, [_p, _p, _p]),
     "rt_sym_eig_values": (_int, [_p, _p, _i64, _p, _p]),
     "rt_sym_eig_vectors": (_int, [_p, _i64, _i64, _p, _p]),
     "rt_host_jacobi_eigh": (_int, [_p, _i64, _p, _p, _int, C.POINTER(_int)]),
@@ -59,6 +60,14 @@ class SweepDesc(C.Structure):
                 ("bdf2", _int), ("indptr", _p), ("indices", _p), ("V", _p), ("mass_values", _p), ("n_terms", _i64),
                 ("term_values", _p), ("term_coef", _p), ("tril_values", _p), ("n_rhs", _i64), ("rhs_terms", _p),
                 ("rhs_coef", _p)]
+
+
+class HSweepDesc(C.Structure):
+    """rt_hsweep_desc of include/romtime_hip.h."""
+
+    _fields_ = [("r", _i64), ("n_mu", _i64), ("nt", _i64), ("dt", C.c_double), ("bdf2", _int), ("m_mass", _i64),
+                ("m_lin", _i64), ("m_nl", _i64), ("m_rhs", _i64), ("Z", _p), ("Zf", _p), ("F_mass", _p), ("F_lin", _p),
+                ("F_rhs", _p), ("W", _p), ("C_nl", _p), ("S_nl", _p)]
 
 
 _lib = None

@@ -68,6 +68,57 @@ __global__ void sweep_store_kernel(const double* __restrict__ x, double* __restr
   }
 }
 
+// ---- hyper-reduced sweep -----------------------------------------------------------------------------------
+// G[b] = [ bdf F_mass | dt F_lin | dt S (W u* + C) ]  (one row of interpolation coefficients per parameter point)
+__global__ void hsweep_coef_kernel(const double* __restrict__ Fm, const double* __restrict__ Fl,
+                                   const double* __restrict__ W, const double* __restrict__ Cn,
+                                   const double* __restrict__ Sn, const double* __restrict__ un,
+                                   const double* __restrict__ unm1, int extrapolate, int mm, int ml, int mn, int r,
+                                   double bdf, double dt, double* __restrict__ G) {
+  extern __shared__ double su[];
+  const int b = blockIdx.x, t = threadIdx.x, M = mm + ml + mn;
+  for (int j = t; j < r; j += blockDim.x) {
+    const double u = un[(long)b * r + j];
+    su[j] = extrapolate ? 2.0 * u - unm1[(long)b * r + j] : u;
+  }
+  __syncthreads();
+  const double sc = Sn ? Sn[b] : 1.0;
+  for (int e = t; e < M; e += blockDim.x) {
+    double g;
+    if (e < mm) {
+      g = bdf * Fm[(long)b * mm + e];
+    } else if (e < mm + ml) {
+      g = dt * Fl[(long)b * ml + (e - mm)];
+    } else {
+      const int q = e - mm - ml;
+      double acc = Cn ? Cn[(long)b * mn + q] : 0.0;
+      const double* w = W + (long)q * r;
+      for (int j = 0; j < r; ++j) acc = fma(w[j], su[j], acc);
+      g = dt * sc * acc;
+    }
+    G[(long)b * M + e] = g;
+  }
+}
+
+// rhs[b] = M_N[b] (c0 u_n[b] + c1 u_nm1[b]) + dt Zf^T F_rhs[b]
+__global__ void hsweep_rhs_kernel(const double* __restrict__ MN, const double* __restrict__ un,
+                                  const double* __restrict__ unm1, double c0, double c1, double dt,
+                                  const double* __restrict__ Ff, const double* __restrict__ Zf, int mf, int r,
+                                  double* __restrict__ rhs) {
+  extern __shared__ double su[];
+  const int b = blockIdx.x, t = threadIdx.x;
+  if (t < r) su[t] = c0 * un[(long)b * r + t] + c1 * unm1[(long)b * r + t];
+  __syncthreads();
+  if (t < r) {
+    const double* M = MN + (long)b * r * r + (long)t * r;
+    double acc = 0.0;
+    for (int j = 0; j < r; ++j) acc = fma(M[j], su[j], acc);
+    double f = 0.0;
+    for (int e = 0; e < mf; ++e) f = fma(Ff[(long)b * mf + e], Zf[(long)e * r + t], f);
+    rhs[(long)b * r + t] = fma(dt, f, acc);
+  }
+}
+
 }  // namespace
 
 extern "C" int rt_rom_bdf_sweep(rt_ctx* ctx, const rt_sweep_desc* d, double* uN_out) {
@@ -158,6 +209,70 @@ extern "C" int rt_rom_bdf_sweep(rt_ctx* ctx, const rt_sweep_desc* d, double* uN_
     if (rc != RT_OK) return rc;
     rc = rt_gemm_nn(ctx, d->V, r, RT_ROW_MAJOR, xT, B, N, r, B, uh, N, RT_COL_MAJOR);
     if (rc != RT_OK) return rc;
+  }
+  return RT_OK;
+}
+
+// Hyper-reduced online sweep: every reduced operator is an interpolation expansion sum_e g_e Z_e whose
+// coefficients g are the operator's own entries at its (M)DEIM entries (tables for the (mu,t)-dependent
+// operators, an affine map of u_N* for the state-dependent one).  Per step: one small kernel builds the
+// coefficient rows, two skinny GEMMs on the matrix cores give K_N and M_N for all parameter points, then the
+// right-hand side, the reduced solve (inverse tracking) and the store.  Nothing of size N_h exists here.
+extern "C" int rt_hrom_bdf_sweep(rt_ctx* ctx, const rt_hsweep_desc* d, double* uN_out) {
+  if (!ctx) return RT_ERR_ARG;
+  RT_ARG_CHECK(ctx, d && uN_out);
+  RT_ARG_CHECK(ctx, d->r >= 1 && d->r <= 128 && d->n_mu >= 1 && d->nt >= 1);
+  RT_ARG_CHECK(ctx, d->m_mass >= 1 && d->m_lin >= 0 && d->m_nl >= 0 && d->m_rhs >= 0 && d->Z && d->F_mass);
+  RT_ARG_CHECK(ctx, (d->m_lin == 0 || d->F_lin) && (d->m_nl == 0 || d->W) && (d->m_rhs == 0 || (d->Zf && d->F_rhs)));
+  const long r = d->r, B = d->n_mu, nt = d->nt, mm = d->m_mass, ml = d->m_lin, mn = d->m_nl, mf = d->m_rhs;
+  const long M = mm + ml + mn, rr = r * r;
+  hipStream_t st = ctx->stream;
+  size_t off = 0;
+  auto take = [&off](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
+  const size_t oG = take(sizeof(double) * B * M), oKN = take(sizeof(double) * B * rr), oMN = take(sizeof(double) * B * rr),
+               oRhs = take(sizeof(double) * B * r), oUn = take(sizeof(double) * B * r), oUm = take(sizeof(double) * B * r),
+               oXi = take(sizeof(double) * B * rr), oInfo = take(sizeof(int) * B);
+  void* base = nullptr;
+  int rc = rt_scratch2(ctx, off, &base);
+  if (rc != RT_OK) return rc;
+  char* b8 = static_cast<char*>(base);
+  double* G = reinterpret_cast<double*>(b8 + oG);
+  double* KN = reinterpret_cast<double*>(b8 + oKN);
+  double* MN = reinterpret_cast<double*>(b8 + oMN);
+  double* rhs = reinterpret_cast<double*>(b8 + oRhs);
+  double* un = reinterpret_cast<double*>(b8 + oUn);
+  double* unm1 = reinterpret_cast<double*>(b8 + oUm);
+  double* Xinv = reinterpret_cast<double*>(b8 + oXi);
+  int* info = reinterpret_cast<int*>(b8 + oInfo);
+  RT_HIP_CHECK(ctx, hipMemsetAsync(un, 0, sizeof(double) * B * r, st));
+  RT_HIP_CHECK(ctx, hipMemsetAsync(unm1, 0, sizeof(double) * B * r, st));
+
+  for (long step = 0; step < nt; ++step) {
+    const bool second = d->bdf2 && step > 0;
+    const double* Fm = d->F_mass + step * B * mm;
+    hipLaunchKernelGGL(hsweep_coef_kernel, dim3((unsigned)B), dim3(256), sizeof(double) * r, st, Fm,
+                       ml ? d->F_lin + step * B * ml : nullptr, d->W, d->C_nl ? d->C_nl + step * B * mn : nullptr,
+                       d->S_nl ? d->S_nl + step * B : nullptr, un, unm1, d->bdf2 ? 1 : 0, (int)mm, (int)ml, (int)mn,
+                       (int)r, second ? 1.5 : 1.0, d->dt, G);
+    RT_HIP_CHECK(ctx, hipGetLastError());
+    // K_N[b][ij] = sum_e G[b][e] Z[e][ij];  M_N[b][ij] = sum_{e < m_mass} F_mass[b][e] Z[e][ij]
+    rc = rt_gemm_strided(ctx, G, 1, M, d->Z, rr, 1, M, B, rr, KN, rr, 1, false, false);
+    if (rc != RT_OK) return rc;
+    rc = rt_gemm_strided(ctx, Fm, 1, mm, d->Z, rr, 1, mm, B, rr, MN, rr, 1, false, false);
+    if (rc != RT_OK) return rc;
+    const double c0 = d->bdf2 ? 2.0 : 1.0, c1 = d->bdf2 ? -0.5 : 0.0;
+    hipLaunchKernelGGL(hsweep_rhs_kernel, dim3((unsigned)B), dim3(128), sizeof(double) * r, st, MN, un, unm1, c0, c1,
+                       d->dt, mf ? d->F_rhs + step * B * mf : nullptr, d->Zf, (int)mf, (int)r, rhs);
+    RT_HIP_CHECK(ctx, hipGetLastError());
+    rc = rt_newton_solve_batched(ctx, KN, Xinv, rhs, r, B, step > 0 ? 1 : 0, info);
+    if (rc == RT_OK)
+      rc = rt_dense_solve_batched_if(ctx, KN, rhs, r, B, info, info);
+    else if (rc == RT_ERR_UNSUPPORTED)
+      rc = rt_dense_solve_batched(ctx, KN, rhs, r, B, info);
+    if (rc != RT_OK) return rc;
+    hipLaunchKernelGGL(sweep_store_kernel, dim3((unsigned)B), dim3(128), 0, st, rhs, un, unm1, uN_out, step, nt, (int)r,
+                       d->bdf2 ? 1 : 0);
+    RT_HIP_CHECK(ctx, hipGetLastError());
   }
   return RT_OK;
 }

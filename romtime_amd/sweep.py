@@ -41,3 +41,85 @@ def rom_bdf_sweep(V, indptr, indices, mass, terms, term_coef, tril, rhs_terms, r
                      rhs_coef=ptr(rcoef_d))
     ctx.check(ctx.lib.rt_rom_bdf_sweep(ctx.handle, C.byref(desc), _p(out.data_ptr())), "rt_rom_bdf_sweep")
     return out
+
+
+def hrom_bdf_sweep(mass, lin, nl, rhs, dt, bdf2=True):
+    """Hyper-reduced online sweep on the device (``rt_hrom_bdf_sweep``): the time loop of
+    ``RomConstructor*.solve`` with every reduced operator obtained by (M)DEIM interpolation,
+    ``interpolate(which=ROM)`` (deim.py:416-452, mdeim.py:230-261), for all parameter points at once.
+
+    ``mass``: one term; ``lin``: list of terms; ``rhs``: list of vector terms.  A term is a dict with ``PT_U``
+    (m x m), ``basis_rom`` (r^2 x m, or r x m for vectors) - the attributes of a projected reductor - and ``F``
+    (nt x n_mu x m): the operator's own entries at the reductor's interpolation entries for every step and
+    parameter point (what ``assemble(mu, t, entries=dofs)`` returns).  ``nl``: None or a dict with ``PT_U``,
+    ``basis_rom``, ``W`` (m x r), optional ``C`` (nt x n_mu x m) and ``S`` (nt x n_mu): entries = S (W u_N* + C).
+    The theta solve is folded into the expansion once (Z = basis_rom PT_U^-1); the loop then never touches anything
+    of size N_h.  Returns ``uN`` (n_mu, nt, r) as a CUDA tensor."""
+    from ._lib import HSweepDesc
+
+    ctx = Context.current()
+
+    def fold(term):  # rows = the r x r (or r) arrays multiplied by each local entry
+        return np.linalg.solve(np.asarray(term["PT_U"], dtype=np.float64).T, np.asarray(term["basis_rom"], dtype=np.float64).T)
+
+    blocks = [fold(mass)] + [fold(t) for t in lin] + ([fold(nl)] if nl is not None else [])
+    rr = blocks[0].shape[1]
+    r = int(round(np.sqrt(rr)))
+    assert r * r == rr and all(bk.shape[1] == rr for bk in blocks), "matrix terms must be r^2 x m"
+    nt, n_mu, m_mass = np.asarray(mass["F"]).shape
+    m_lin = sum(np.asarray(t["F"]).shape[2] for t in lin)
+    m_nl = 0 if nl is None else np.asarray(nl["W"]).shape[0]
+    dev = lambda a: ops.to_device(np.ascontiguousarray(a, dtype=np.float64))
+    Z = dev(np.vstack(blocks))
+    Fm = dev(mass["F"])
+    Fl = dev(np.concatenate([np.asarray(t["F"]) for t in lin], axis=2)) if lin else None
+    Zf = dev(np.vstack([fold(t) for t in rhs])) if rhs else None
+    Ff = dev(np.concatenate([np.asarray(t["F"]) for t in rhs], axis=2)) if rhs else None
+    m_rhs = 0 if Zf is None else Zf.shape[0]
+    W = dev(nl["W"]) if nl is not None else None
+    Cn = dev(nl["C"]) if nl is not None and nl.get("C") is not None else None
+    Sn = dev(nl["S"]) if nl is not None and nl.get("S") is not None else None
+    out = torch.empty((n_mu, nt, r), dtype=torch.float64, device=Z.device)
+    ptr = lambda t: _p(t.data_ptr()) if t is not None else _p(None)
+    desc = HSweepDesc(r=r, n_mu=n_mu, nt=nt, dt=float(dt), bdf2=int(bool(bdf2)), m_mass=m_mass, m_lin=m_lin, m_nl=m_nl,
+                      m_rhs=m_rhs, Z=ptr(Z), Zf=ptr(Zf), F_mass=ptr(Fm), F_lin=ptr(Fl), F_rhs=ptr(Ff), W=ptr(W),
+                      C_nl=ptr(Cn), S_nl=ptr(Sn))
+    ctx.check(ctx.lib.rt_hrom_bdf_sweep(ctx.handle, C.byref(desc), _p(out.data_ptr())), "rt_hrom_bdf_sweep")
+    return out
+
+
+def hrom_terms_from_rom(rom, mus):
+    """Term dictionaries for :func:`hrom_bdf_sweep` from a ``RomConstructorNonlinear`` whose operators are all
+    hyper-reduced and projected (``add_hyper_reductor`` + ``project_reductors``): the tables hold what each
+    reductor's ``assemble(mu, t, entries=dofs)`` returns at every step for every parameter point - the same calls
+    the host loop ``rom.solve`` makes one by one (rom.py:877-929 through deim.py:429-433).
+
+    The state-dependent operator must be an affine map of the state that does not depend on (mu, t) (a trilinear
+    form on a reference mesh plus constant boundary entries), which is checked; other FOMs fill the ``C`` / ``S``
+    fields of the ``nl`` term themselves."""
+    fom = rom.fom
+    nt, dt = fom.domain["nt"], fom.dt
+    ts = dt * np.arange(1, nt + 1)
+
+    def table(red):
+        return np.array([[red._local_values(mu, t) for mu in mus] for t in ts])
+
+    def term(red):
+        return dict(PT_U=red.PT_U, basis_rom=red.basis_rom, F=table(red))
+
+    need = dict(mass=rom.mdeim_Mh, stiffness=rom.mdeim_Ah, convection=rom.mdeim_Ch, nonlinear_lifting=rom.mdeim_Nh_hat,
+                trilinear=rom.mdeim_Nh, lifting=rom.deim_fgh)
+    missing = [k for k, v in need.items() if not v]
+    if missing:
+        raise ValueError(f"operators without a hyper-reductor: {missing}")
+    V = rom.basis
+    red = rom.mdeim_Nh
+    c0 = red._local_values(mus[0], ts[0], u_n=np.zeros(V.shape[0]))  # constant entries (Dirichlet rows)
+    W = np.stack([red._local_values(mus[0], ts[0], u_n=V[:, k]) - c0 for k in range(V.shape[1])], axis=1)
+    probe = np.random.RandomState(0).standard_normal(V.shape[1])
+    again = red._local_values(mus[-1], ts[-1], u_n=V @ probe)
+    if not np.allclose(again, W @ probe + c0, rtol=1e-10, atol=1e-12 * max(1.0, np.abs(W).max())):
+        raise NotImplementedError("state-dependent operator is not a (mu, t)-independent affine map of the state")
+    nl = dict(PT_U=red.PT_U, basis_rom=red.basis_rom, W=W, C=np.broadcast_to(c0, (nt, len(mus), c0.size)).copy())
+    return dict(mass=term(need["mass"]), lin=[term(need[k]) for k in ("stiffness", "convection", "nonlinear_lifting")],
+                nl=nl, rhs=[term(need["lifting"])], dt=dt, bdf2=(fom.BDF_SCHEME == "2"))

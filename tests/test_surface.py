@@ -246,6 +246,77 @@ def check_rom_offline_and_hyper_reduced():
         rom.add_hyper_reductor(md, "no-such-operator")
 
 
+def _fully_hyper_reduced_rom():
+    """MockBurgers ROM with an (M)DEIM on every operator: mass, stiffness, convection, nonlinear lifting (MDEIM),
+    trilinear (N-MDEIM over the reduced basis, nonlinear.py:159-212) and the lifting vector (DEIM)."""
+    from scipy.stats.distributions import uniform
+
+    from romtime_amd import (DiscreteEmpiricalInterpolation, MatrixDiscreteEmpiricalInterpolation,
+                             MatrixDiscreteEmpiricalInterpolationNonlinear, RomConstructorNonlinear)
+    from romtime_amd.conventions import OperatorType, RomParameters
+
+    fom = _burgers(True, nx=60, nt=14)
+    mus = [dict(alpha_0=0.05 + 0.02 * i, delta=0.3, omega=9.0 + i) for i in range(3)]
+    srom = RomConstructorNonlinear(fom=fom, grid=None, name="srom")
+    srom.setup(rnd=0)
+    srom.build_reduced_basis(mu_space=mus, tolerances={RomParameters.TOL_TIME: None, RomParameters.TOL_MU: None})
+    rom = srom.truncate(max(srom.N - 8, 0)) if srom.N > 8 else srom
+    grid = dict(alpha_0=uniform(0.04, 0.08), delta=uniform(0.29, 0.02), omega=uniform(8.5, 3.0))
+    tw = {"ts": np.linspace(0.01, 0.5, 8), "num_snapshots": 4}
+    rnd = lambda: np.random.RandomState(1)
+    ops_m = dict(mass=(fom.assemble_mass, OperatorType.MASS), stiffness=(fom.assemble_stiffness, OperatorType.STIFFNESS),
+                 convection=(fom.assemble_convection, OperatorType.CONVECTION),
+                 nonlinear_lifting=(fom.assemble_nonlinear_lifting, OperatorType.NONLINEAR_LIFTING))
+    for name, (assemble, which) in ops_m.items():
+        md = MatrixDiscreteEmpiricalInterpolation(name=name, assemble=assemble, grid=grid, tree_walk_params=tw)
+        md.setup(rnd=rnd())
+        md.run()
+        rom.add_hyper_reductor(md, which)
+    nm = MatrixDiscreteEmpiricalInterpolationNonlinear(name="trilinear", assemble=fom.assemble_trilinear, grid=grid,
+                                                       tree_walk_params=tw)
+    nm.setup(rnd=rnd(), u_n=np.linspace(0.0, 1.0, fom.Nh))
+    nm.run(u_n=rom.basis)
+    rom.add_hyper_reductor(nm, OperatorType.TRILINEAR)
+    dl = DiscreteEmpiricalInterpolation(name="lifting", assemble=fom.assemble_lifting, grid=grid, tree_walk_params=tw)
+    dl.setup(rnd=rnd())
+    dl.run()
+    rom.add_hyper_reductor(dl, OperatorType.LIFTING)
+    rom.project_reductors()
+    return fom, rom, mus
+
+
+def check_hyper_reduced_loop_matches_oracle(device_sweep):
+    """The fully hyper-reduced online loop: class surface (host-driven, the reference's call sequence) ==
+    oracle.hrom_solve on the tables the reductors produce == the device-resident sweep (GPU runs only)."""
+    from romtime_amd.conventions import Stage
+    from romtime_amd.sweep import hrom_bdf_sweep, hrom_terms_from_rom
+
+    fom, rom, mus = _fully_hyper_reduced_rom()
+    assert rom.mdeim_Nh.basis_rom.shape[0] == rom.N ** 2 and rom.deim_fgh.basis_rom.shape[0] == rom.N
+    terms = hrom_terms_from_rom(rom, mus)
+    r, nt = rom.N, fom.domain["nt"]
+    trajectories = []
+    for b, mu in enumerate(mus):
+        rom.solve(mu=mu, step=Stage.ONLINE)
+        host = rom.solutions.rom.copy()
+        ref = oracle.hrom_solve(terms["mass"], terms["lin"], terms["nl"], terms["rhs"], b, r, nt, terms["dt"],
+                                terms["bdf2"])
+        assert host.shape == ref.shape == (r, nt)
+        assert np.linalg.norm(host - ref) <= 1e-9 * np.linalg.norm(ref), b
+        trajectories.append(ref)
+    # the hyper-reduced ROM still tracks the full-order solution it was trained on
+    fom.update_parametrization(mus[1])
+    fom.solve()
+    rom.solve(mu=mus[1], step=Stage.ONLINE)
+    err = np.linalg.norm(rom.solutions.fom - fom.solutions.fom) / np.linalg.norm(fom.solutions.fom)
+    assert err < 5e-2, err  # coarse sanity bar (14 steps, 8 modes); parity is the 1e-9 / 1e-10 checks above
+    if device_sweep:
+        uN = hrom_bdf_sweep(terms["mass"], terms["lin"], terms["nl"], terms["rhs"], terms["dt"], terms["bdf2"])
+        uN = uN.cpu().numpy()
+        for b, ref in enumerate(trajectories):
+            assert np.linalg.norm(uN[b].T - ref) <= 1e-10 * np.linalg.norm(ref), b
+
+
 def check_to_rom_roundtrip():
     from romtime_amd import RomConstructor
 
@@ -341,6 +412,10 @@ def test_to_rom_hostlogic(cpu_ops):
     check_to_rom_roundtrip()
 
 
+def test_hyper_reduced_loop_hostlogic(cpu_ops):
+    check_hyper_reduced_loop_matches_oracle(device_sweep=False)
+
+
 def test_artefact_round_trip_hostlogic(cpu_ops, golden_deim, tmp_path, monkeypatch):
     check_artefact_round_trip(golden_deim, tmp_path, monkeypatch)
 
@@ -399,6 +474,11 @@ def test_rom_offline_hip():
 @pytest.mark.gpu
 def test_to_rom_hip():
     check_to_rom_roundtrip()
+
+
+@pytest.mark.gpu
+def test_hyper_reduced_loop_hip():
+    check_hyper_reduced_loop_matches_oracle(device_sweep=True)
 
 
 def check_orth_odd_shapes():
