@@ -56,8 +56,17 @@ int rt_gemm_strided(rt_ctx* ctx, const double* A, int64_t a_ks, int64_t a_ms, co
 int rt_gram128(rt_ctx* ctx, const double* X, int64_t ks, int64_t ms, int64_t K, int64_t n, double* G);
 
 // Newton-Schulz inverse tracking solve for the online sweep (solve.hip); RT_ERR_UNSUPPORTED for r > 80.
+struct rt_newton_rhs {  // b = M_N (c0 u^n + c1 u^{n-1}) + dt Zf^T F_rhs, per system; MN == nullptr: rhs is given
+  const double* MN;    // B x r x r
+  const double* un;    // B x r
+  const double* unm1;  // B x r
+  double c0, c1, dt;
+  const double* Ff;    // B x mf
+  const double* Zf;    // mf x r
+  int mf;
+};
 int rt_newton_solve_batched(rt_ctx* ctx, const double* K, double* Xinv, double* rhs, int64_t r, int64_t B,
-                            int have_prev, int* info);
+                            int have_prev, int* info, const rt_newton_rhs* recipe = nullptr);
 int rt_dense_solve_batched_if(rt_ctx* ctx, double* K, double* rhs, int64_t r, int64_t B, int* info, const int* only_if);
 
 // Fused SpMM + V^T(.) projection (project_fused.hip); RT_ERR_UNSUPPORTED for r > 128.  `stage_table` is the

@@ -162,7 +162,8 @@ __device__ __forceinline__ double ns_block_max(double x, double* s_red, int tid)
 __global__ __launch_bounds__(NS_THREADS) void newton_solve_kernel(const double* __restrict__ K,
                                                                   double* __restrict__ Xinv,
                                                                   double* __restrict__ rhs, int r, int S,
-                                                                  int have_prev, int* __restrict__ info) {
+                                                                  int have_prev, int* __restrict__ info,
+                                                                  const rt_newton_rhs rq) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int tr = (r + 15) / 16, rp = tr * 16, ntile = tr * tr;
   double* sK = sm;                    // [rp][S], padded with the identity
@@ -183,7 +184,25 @@ __global__ __launch_bounds__(NS_THREADS) void newton_solve_kernel(const double* 
       sK[i * S + j] = in ? Kb[i * r + j] : eye;
       sX[i * S + j] = (in && have_prev) ? Xb[i * r + j] : eye;
     }
-  if (tid < r) s_vec[0][tid] = rb[tid];
+  if (rq.MN) {
+    // right-hand side formed here: b = M_N (c0 u^n + c1 u^{n-1}) + dt Zf^T F_rhs (also left in rhs for the fallback)
+    if (tid < r) s_vec[1][tid] = rq.c0 * rq.un[(size_t)blockIdx.x * r + tid] + rq.c1 * rq.unm1[(size_t)blockIdx.x * r + tid];
+    __syncthreads();
+    const double* Mb = rq.MN + (size_t)blockIdx.x * r * r;
+    for (int i = wid; i < r; i += NS_THREADS / 64) {
+      double acc = 0.0;
+      for (int j = lane; j < r; j += 64) acc = fma(Mb[(size_t)i * r + j], s_vec[1][j], acc);
+      double f = 0.0;
+      for (int e = lane; e < rq.mf; e += 64) f = fma(rq.Ff[(size_t)blockIdx.x * rq.mf + e], rq.Zf[(size_t)e * r + i], f);
+      const double v = rtw::wave_sum(fma(rq.dt, f, acc));
+      if (lane == 0) {
+        s_vec[0][i] = v;
+        rb[i] = v;
+      }
+    }
+  } else if (tid < r) {
+    s_vec[0][tid] = rb[tid];
+  }
   __syncthreads();
 
   // C(ti, tj) = sum_k A[16 ti + i][k] B[k][16 tj + j]; tile t = wid + 8 q belongs to this wave (q < 4 as r <= 80)
@@ -340,9 +359,10 @@ static int dense_solve_launch(rt_ctx* ctx, double* K, double* rhs, int64_t r, in
 
 // Internal (sweep.hip): solve K_b x_b = rhs_b while tracking K_b^-1 in Xinv (B x r x r, caller-owned, carried
 // from call to call).  have_prev = 0 on the first call.  RT_ERR_UNSUPPORTED when three padded r x r matrices
-// do not fit the LDS (r > 80): the caller uses rt_dense_solve_batched.
+// do not fit the LDS (r > 80): the caller uses rt_dense_solve_batched.  With `recipe` the kernel forms the
+// right-hand side itself (and leaves it in rhs) instead of reading it.
 int rt_newton_solve_batched(rt_ctx* ctx, const double* K, double* Xinv, double* rhs, int64_t r, int64_t B,
-                            int have_prev, int* info) {
+                            int have_prev, int* info, const rt_newton_rhs* recipe) {
   const int rp = (int)((r + 15) / 16) * 16;
   int S = rp;
   while (S % 4 != 2) ++S;  // 2 S == 4 (mod 8): the 16 rows of an A-operand read fall in distinct LDS banks
@@ -354,8 +374,10 @@ int rt_newton_solve_batched(rt_ctx* ctx, const double* K, double* Xinv, double* 
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
     attr_set = true;
   }
+  rt_newton_rhs rq{};
+  if (recipe) rq = *recipe;
   hipLaunchKernelGGL(newton_solve_kernel, dim3((unsigned)B), dim3(NS_THREADS), lds, ctx->stream, K, Xinv, rhs, (int)r, S,
-                     have_prev, info);
+                     have_prev, info, rq);
   RT_HIP_CHECK(ctx, hipGetLastError());
   return RT_OK;
 }

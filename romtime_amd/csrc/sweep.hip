@@ -70,17 +70,32 @@ __global__ void sweep_store_kernel(const double* __restrict__ x, double* __restr
 
 // ---- hyper-reduced sweep -----------------------------------------------------------------------------------
 // G[b] = [ bdf F_mass | dt F_lin | dt S (W u* + C) ]  (one row of interpolation coefficients per parameter point)
-__global__ void hsweep_coef_kernel(const double* __restrict__ Fm, const double* __restrict__ Fl,
-                                   const double* __restrict__ W, const double* __restrict__ Cn,
-                                   const double* __restrict__ Sn, const double* __restrict__ un,
-                                   const double* __restrict__ unm1, int extrapolate, int mm, int ml, int mn, int r,
-                                   double bdf, double dt, double* __restrict__ G) {
-  extern __shared__ double su[];
+// and G[B + b] = [ F_mass | 0 | 0 ], so that ONE skinny GEMM with Z yields K_N (rows 0..B-1) and M_N (rows B..2B-1)
+// Optionally first closes a step (x -> u^n, u^n -> u^{n-1}, trajectory), then builds the coefficient rows of the
+// next one from the updated state: one launch between two steps instead of two.
+__global__ void hsweep_advance_kernel(const double* __restrict__ x, double* __restrict__ un,
+                                      double* __restrict__ unm1, double* __restrict__ out, long step_done, long nt,
+                                      int keep_prev, int do_store, int do_coef, const double* __restrict__ Fm,
+                                      const double* __restrict__ Fl, const double* __restrict__ W,
+                                      const double* __restrict__ Cn, const double* __restrict__ Sn, int extrapolate,
+                                      int mm, int ml, int mn, int r, double bdf, double dt, double* __restrict__ G) {
+  extern __shared__ double su[];  // u* of the coming step
   const int b = blockIdx.x, t = threadIdx.x, M = mm + ml + mn;
   for (int j = t; j < r; j += blockDim.x) {
-    const double u = un[(long)b * r + j];
-    su[j] = extrapolate ? 2.0 * u - unm1[(long)b * r + j] : u;
+    double u = un[(long)b * r + j], up = unm1[(long)b * r + j];
+    if (do_store) {
+      const double v = x[(long)b * r + j];
+      if (keep_prev) {
+        unm1[(long)b * r + j] = u;
+        up = u;
+      }
+      un[(long)b * r + j] = v;
+      out[((long)b * nt + step_done) * r + j] = v;
+      u = v;
+    }
+    su[j] = extrapolate ? 2.0 * u - up : u;
   }
+  if (!do_coef) return;
   __syncthreads();
   const double sc = Sn ? Sn[b] : 1.0;
   for (int e = t; e < M; e += blockDim.x) {
@@ -97,6 +112,7 @@ __global__ void hsweep_coef_kernel(const double* __restrict__ Fm, const double* 
       g = dt * sc * acc;
     }
     G[(long)b * M + e] = g;
+    G[(long)(gridDim.x + b) * M + e] = (e < mm) ? Fm[(long)b * mm + e] : 0.0;
   }
 }
 
@@ -229,7 +245,7 @@ extern "C" int rt_hrom_bdf_sweep(rt_ctx* ctx, const rt_hsweep_desc* d, double* u
   hipStream_t st = ctx->stream;
   size_t off = 0;
   auto take = [&off](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
-  const size_t oG = take(sizeof(double) * B * M), oKN = take(sizeof(double) * B * rr), oMN = take(sizeof(double) * B * rr),
+  const size_t oG = take(sizeof(double) * 2 * B * M), oKN = take(sizeof(double) * 2 * B * rr),
                oRhs = take(sizeof(double) * B * r), oUn = take(sizeof(double) * B * r), oUm = take(sizeof(double) * B * r),
                oXi = take(sizeof(double) * B * rr), oInfo = take(sizeof(int) * B);
   void* base = nullptr;
@@ -238,7 +254,7 @@ extern "C" int rt_hrom_bdf_sweep(rt_ctx* ctx, const rt_hsweep_desc* d, double* u
   char* b8 = static_cast<char*>(base);
   double* G = reinterpret_cast<double*>(b8 + oG);
   double* KN = reinterpret_cast<double*>(b8 + oKN);
-  double* MN = reinterpret_cast<double*>(b8 + oMN);
+  double* MN = KN + B * rr;  // second half of the stacked product
   double* rhs = reinterpret_cast<double*>(b8 + oRhs);
   double* un = reinterpret_cast<double*>(b8 + oUn);
   double* unm1 = reinterpret_cast<double*>(b8 + oUm);
@@ -247,31 +263,33 @@ extern "C" int rt_hrom_bdf_sweep(rt_ctx* ctx, const rt_hsweep_desc* d, double* u
   RT_HIP_CHECK(ctx, hipMemsetAsync(un, 0, sizeof(double) * B * r, st));
   RT_HIP_CHECK(ctx, hipMemsetAsync(unm1, 0, sizeof(double) * B * r, st));
 
+  auto advance = [&](long next, int do_store) {  // close step next-1 (if any) and prepare the rows of step `next`
+    const bool has_next = next < nt;
+    const long s2 = has_next ? next : 0;
+    hipLaunchKernelGGL(hsweep_advance_kernel, dim3((unsigned)B), dim3(256), sizeof(double) * r, st, rhs, un, unm1, uN_out,
+                       next - 1, nt, d->bdf2 ? 1 : 0, do_store, has_next ? 1 : 0, d->F_mass + s2 * B * mm,
+                       ml ? d->F_lin + s2 * B * ml : nullptr, d->W, d->C_nl ? d->C_nl + s2 * B * mn : nullptr,
+                       d->S_nl ? d->S_nl + s2 * B : nullptr, d->bdf2 ? 1 : 0, (int)mm, (int)ml, (int)mn, (int)r,
+                       (d->bdf2 && next > 0) ? 1.5 : 1.0, d->dt, G);
+  };
+  advance(0, 0);
+  RT_HIP_CHECK(ctx, hipGetLastError());
+  const double c0 = d->bdf2 ? 2.0 : 1.0, c1 = d->bdf2 ? -0.5 : 0.0;
   for (long step = 0; step < nt; ++step) {
-    const bool second = d->bdf2 && step > 0;
-    const double* Fm = d->F_mass + step * B * mm;
-    hipLaunchKernelGGL(hsweep_coef_kernel, dim3((unsigned)B), dim3(256), sizeof(double) * r, st, Fm,
-                       ml ? d->F_lin + step * B * ml : nullptr, d->W, d->C_nl ? d->C_nl + step * B * mn : nullptr,
-                       d->S_nl ? d->S_nl + step * B : nullptr, un, unm1, d->bdf2 ? 1 : 0, (int)mm, (int)ml, (int)mn,
-                       (int)r, second ? 1.5 : 1.0, d->dt, G);
-    RT_HIP_CHECK(ctx, hipGetLastError());
-    // K_N[b][ij] = sum_e G[b][e] Z[e][ij];  M_N[b][ij] = sum_{e < m_mass} F_mass[b][e] Z[e][ij]
-    rc = rt_gemm_strided(ctx, G, 1, M, d->Z, rr, 1, M, B, rr, KN, rr, 1, false, false);
+    // [K_N; M_N][b][ij] = sum_e G[b][e] Z[e][ij]  (2 B rows)
+    rc = rt_gemm_strided(ctx, G, 1, M, d->Z, rr, 1, M, 2 * B, rr, KN, rr, 1, false, false);
     if (rc != RT_OK) return rc;
-    rc = rt_gemm_strided(ctx, Fm, 1, mm, d->Z, rr, 1, mm, B, rr, MN, rr, 1, false, false);
-    if (rc != RT_OK) return rc;
-    const double c0 = d->bdf2 ? 2.0 : 1.0, c1 = d->bdf2 ? -0.5 : 0.0;
-    hipLaunchKernelGGL(hsweep_rhs_kernel, dim3((unsigned)B), dim3(128), sizeof(double) * r, st, MN, un, unm1, c0, c1,
-                       d->dt, mf ? d->F_rhs + step * B * mf : nullptr, d->Zf, (int)mf, (int)r, rhs);
-    RT_HIP_CHECK(ctx, hipGetLastError());
-    rc = rt_newton_solve_batched(ctx, KN, Xinv, rhs, r, B, step > 0 ? 1 : 0, info);
-    if (rc == RT_OK)
+    rt_newton_rhs rq{MN, un, unm1, c0, c1, d->dt, mf ? d->F_rhs + step * B * mf : nullptr, d->Zf, (int)mf};
+    rc = rt_newton_solve_batched(ctx, KN, Xinv, rhs, r, B, step > 0 ? 1 : 0, info, &rq);
+    if (rc == RT_OK) {
       rc = rt_dense_solve_batched_if(ctx, KN, rhs, r, B, info, info);
-    else if (rc == RT_ERR_UNSUPPORTED)
+    } else if (rc == RT_ERR_UNSUPPORTED) {  // r > 80: right-hand side by its own kernel, then the LU
+      hipLaunchKernelGGL(hsweep_rhs_kernel, dim3((unsigned)B), dim3(128), sizeof(double) * r, st, MN, un, unm1, c0, c1,
+                         d->dt, mf ? d->F_rhs + step * B * mf : nullptr, d->Zf, (int)mf, (int)r, rhs);
       rc = rt_dense_solve_batched(ctx, KN, rhs, r, B, info);
+    }
     if (rc != RT_OK) return rc;
-    hipLaunchKernelGGL(sweep_store_kernel, dim3((unsigned)B), dim3(128), 0, st, rhs, un, unm1, uN_out, step, nt, (int)r,
-                       d->bdf2 ? 1 : 0);
+    advance(step + 1, 1);
     RT_HIP_CHECK(ctx, hipGetLastError());
   }
   return RT_OK;

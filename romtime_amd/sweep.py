@@ -66,15 +66,23 @@ def hrom_bdf_sweep(mass, lin, nl, rhs, dt, bdf2=True):
     rr = blocks[0].shape[1]
     r = int(round(np.sqrt(rr)))
     assert r * r == rr and all(bk.shape[1] == rr for bk in blocks), "matrix terms must be r^2 x m"
-    nt, n_mu, m_mass = np.asarray(mass["F"]).shape
-    m_lin = sum(np.asarray(t["F"]).shape[2] for t in lin)
+    def dev(a):  # tables may already live on the device (torch tensors)
+        if isinstance(a, torch.Tensor):
+            return a.to(dtype=torch.float64).contiguous() if a.is_cuda else ops.to_device(a.numpy())
+        return ops.to_device(np.ascontiguousarray(a, dtype=np.float64))
+
+    def cat(terms):
+        tabs = [dev(t["F"]) for t in terms]
+        return tabs[0] if len(tabs) == 1 else torch.cat(tabs, dim=2).contiguous()
+
+    nt, n_mu, m_mass = tuple(mass["F"].shape)
+    m_lin = sum(int(t["F"].shape[2]) for t in lin)
     m_nl = 0 if nl is None else np.asarray(nl["W"]).shape[0]
-    dev = lambda a: ops.to_device(np.ascontiguousarray(a, dtype=np.float64))
     Z = dev(np.vstack(blocks))
     Fm = dev(mass["F"])
-    Fl = dev(np.concatenate([np.asarray(t["F"]) for t in lin], axis=2)) if lin else None
+    Fl = cat(lin) if lin else None
     Zf = dev(np.vstack([fold(t) for t in rhs])) if rhs else None
-    Ff = dev(np.concatenate([np.asarray(t["F"]) for t in rhs], axis=2)) if rhs else None
+    Ff = cat(rhs) if rhs else None
     m_rhs = 0 if Zf is None else Zf.shape[0]
     W = dev(nl["W"]) if nl is not None else None
     Cn = dev(nl["C"]) if nl is not None and nl.get("C") is not None else None

@@ -217,6 +217,9 @@ def c5h(nt=2000, n_mu=32, N=100_000, r=80, m_lin=40, m_nl=120, m_rhs=20):
               W=nl_full["PT_U"] @ np.concatenate([np.eye(r), np.zeros((m_nl - r, r))], axis=0))
     fN = (V.T @ d["rhs_terms"].T)                                                            # r x F
     rhs = [embed(fN, d["rhs_coef"], m_rhs)]
+    host_terms = (mass, lin, rhs)
+    up = lambda term: dict(term, F=ops.to_device(np.ascontiguousarray(term["F"])))   # tables resident, as in bench.py
+    mass, lin, rhs = up(mass), [up(t) for t in lin], [up(t) for t in rhs]
     args = (mass, lin, nl, rhs, d["dt"])
     hrom_bdf_sweep(*args, bdf2=True)
     torch.cuda.synchronize()
@@ -224,21 +227,21 @@ def c5h(nt=2000, n_mu=32, N=100_000, r=80, m_lin=40, m_nl=120, m_rhs=20):
     uN = hrom_bdf_sweep(*args, bdf2=True)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    # device kernel time only (tables resident): second call minus upload is dominated by H2D of the tables
     ref = rom_bdf_sweep(Vd, d["indptr"], d["indices"], ops.to_device(d["mass"]), ops.to_device(d["terms"]),
                         ops.to_device(d["term_coef"][:nt_direct]), ops.to_device(d["tril"]), ops.to_device(d["rhs_terms"]),
                         ops.to_device(d["rhs_coef"][:nt_direct]), d["dt"], bdf2=True)
     cross = float((uN[:, :nt_direct] - ref).norm() / ref.norm())
     t0 = time.perf_counter()
     small = 5
-    cut = lambda term: dict(term, F=term["F"][:small]) if "F" in term else term
-    oref = oracle.hrom_solve(cut(mass), [cut(t) for t in lin], nl, [cut(t) for t in rhs], 0, r, small, d["dt"], True)
+    cut = lambda term: dict(term, F=term["F"][:small])
+    hm, hl, hr = host_terms
+    oref = oracle.hrom_solve(cut(hm), [cut(t) for t in hl], nl, [cut(t) for t in hr], 0, r, small, d["dt"], True)
     cpu = (time.perf_counter() - t0) / small
     err = float(np.linalg.norm(uN[0, :small].cpu().numpy().T - oref) / np.linalg.norm(oref))
     M = m_lin * 4 + m_nl
     return dict(config=f"C5 hyper-reduced sweep r={r} {n_mu} mu x {nt} BDF2 steps, {M} interpolation coefficients "
                        f"(mass/stiffness/convection/nonlinear-lifting {m_lin} each, trilinear {m_nl}, rhs {m_rhs})",
-                wall_s_incl_table_upload=wall, ms_per_step_all_mu=1e3 * wall / nt, reduced_steps_per_s=nt * n_mu / wall,
+                wall_s=wall, ms_per_step_all_mu=1e3 * wall / nt, reduced_steps_per_s=nt * n_mu / wall,
                 cpu_s_per_reduced_step=cpu, cpu_reduced_steps_per_s=1.0 / cpu, first5_rel_err_vs_oracle=err,
                 rel_diff_vs_direct_device_sweep_first40=cross)
 
