@@ -14,6 +14,7 @@
 // workgroup with a lexicographic (value desc, index asc) order -- np.argmax's tie rule.
 // HBM traffic is the algorithmic 8 N (k+2) bytes per step.
 #include "common.h"
+#include "wave_ops.h"
 
 typedef double d2 __attribute__((ext_vector_type(2)));
 
@@ -40,16 +41,38 @@ __device__ __forceinline__ Top2 top2_merge(const Top2& a, const Top2& b) {
   return o;
 }
 
-__device__ __forceinline__ Top2 top2_wave(Top2 t) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    Top2 o;
-    o.v1 = __shfl_down(t.v1, off);
-    o.i1 = __shfl_down(t.i1, off);
-    o.v2 = __shfl_down(t.v2, off);
-    t = top2_merge(t, o);
-  }
-  return t;
+// Wave-wide merge on the DPP path (wave_ops.h): lanes without a source receive the identity {-1, max, -1}.
+// The merge is associative and commutative on (value desc, index asc), so the result is independent of the tree.
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ Top2 top2_dpp(const Top2& t) {
+  const long long v1 = __double_as_longlong(t.v1), v2 = __double_as_longlong(t.v2);
+  constexpr int NEG1_HI = (int)0xBFF00000;  // -1.0
+  Top2 o;
+  const int v1lo = __builtin_amdgcn_update_dpp(0, (int)v1, CTRL, ROW_MASK, 0xf, false);
+  const int v1hi = __builtin_amdgcn_update_dpp(NEG1_HI, (int)(v1 >> 32), CTRL, ROW_MASK, 0xf, false);
+  const int v2lo = __builtin_amdgcn_update_dpp(0, (int)v2, CTRL, ROW_MASK, 0xf, false);
+  const int v2hi = __builtin_amdgcn_update_dpp(NEG1_HI, (int)(v2 >> 32), CTRL, ROW_MASK, 0xf, false);
+  const int ilo = __builtin_amdgcn_update_dpp(-1, (int)t.i1, CTRL, ROW_MASK, 0xf, false);
+  const int ihi = __builtin_amdgcn_update_dpp(0x7fffffff, (int)(t.i1 >> 32), CTRL, ROW_MASK, 0xf, false);
+  o.v1 = __longlong_as_double(((long long)v1hi << 32) | (unsigned)v1lo);
+  o.v2 = __longlong_as_double(((long long)v2hi << 32) | (unsigned)v2lo);
+  o.i1 = ((long)ihi << 32) | (unsigned)ilo;
+  return o;
+}
+
+__device__ __forceinline__ Top2 top2_wave(Top2 t) {  // result valid in lane 63, returned wave-uniform
+  t = top2_merge(t, top2_dpp<0x111>(t));        // row_shr:1
+  t = top2_merge(t, top2_dpp<0x112>(t));        // row_shr:2
+  t = top2_merge(t, top2_dpp<0x114>(t));        // row_shr:4
+  t = top2_merge(t, top2_dpp<0x118>(t));        // row_shr:8  -> lane 15 of each row: the row's result
+  t = top2_merge(t, top2_dpp<0x142, 0xa>(t));   // row_bcast:15
+  t = top2_merge(t, top2_dpp<0x143, 0xc>(t));   // row_bcast:31 -> lane 63
+  Top2 o;
+  o.v1 = rtw::read_lane(t.v1, 63);
+  o.v2 = rtw::read_lane(t.v2, 63);
+  const int ilo = __builtin_amdgcn_readlane((int)t.i1, 63), ihi = __builtin_amdgcn_readlane((int)(t.i1 >> 32), 63);
+  o.i1 = ((long)ihi << 32) | (unsigned)ilo;
+  return o;
 }
 
 constexpr int RES_THREADS = 256;
