@@ -148,6 +148,7 @@ __global__ __launch_bounds__(PIV_THREADS) void deim_pivot_kernel(const double* _
   __shared__ Top2 s_red[PIV_THREADS / 64];
   __shared__ double s_l[1024];
   __shared__ double s_b[1024];
+  __shared__ double s_part[PIV_THREADS];
   __shared__ long s_p;
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int kp = k - 1;  // step being finished
@@ -169,14 +170,30 @@ __global__ __launch_bounds__(PIV_THREADS) void deim_pivot_kernel(const double* _
   __syncthreads();
   const long p = s_p;
 
-  // 2. border L^-1 with row kp:  l_j = r_j[p] / delta_j (j < kp);  Linv[kp][:] = -l^T Linv, Linv[kp][kp] = 1
+  // 2. border L^-1 with row kp:  l_j = r_j[p] / delta_j (j < kp);  Linv[kp][:] = -l^T Linv, Linv[kp][kp] = 1.
+  //    Eight threads share a column (rows i == part mod 8), so nobody walks more than kp/8 entries of the
+  //    column-strided Linv; the partial sums meet in LDS and are added in a fixed order.
   for (int j = tid; j < kp; j += PIV_THREADS) s_l[j] = R[(long)j * ldr + p] / delta[j];
   __syncthreads();
-  for (int j = tid; j < kp; j += PIV_THREADS) {
-    double acc = 0.0;
-#pragma unroll 8
-    for (int i = j; i < kp; ++i) acc = fma(s_l[i], Linv[(long)i * m + j], acc);
-    Linv[(long)kp * m + j] = -acc;
+  {
+    const int jj = tid & 127, part = tid >> 7;
+    for (int j0 = 0; j0 < kp; j0 += 128) {
+      const int j = j0 + jj;
+      double acc = 0.0;
+      if (j < kp) {
+#pragma unroll 4
+        for (int i = j + part; i < kp; i += PIV_THREADS / 128) acc = fma(s_l[i], Linv[(long)i * m + j], acc);
+      }
+      s_part[part * 128 + jj] = acc;
+      __syncthreads();
+      if (part == 0 && j < kp) {
+        double sum = 0.0;
+#pragma unroll
+        for (int q = 0; q < PIV_THREADS / 128; ++q) sum += s_part[q * 128 + jj];
+        Linv[(long)kp * m + j] = -sum;
+      }
+      __syncthreads();
+    }
   }
   if (tid == 0) Linv[(long)kp * m + kp] = 1.0;
   if (k >= m) return;
@@ -190,8 +207,7 @@ __global__ __launch_bounds__(PIV_THREADS) void deim_pivot_kernel(const double* _
   for (int i = jstart + wid; i < k; i += PIV_THREADS / 64) {
     double acc = 0.0;
     for (int j = jstart + lane; j <= i; j += 64) acc = fma(Linv[(long)i * m + j], s_b[j], acc);
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    acc = rtw::wave_sum(acc);
     if (lane == 0) yt[i] = acc / delta[i];
   }
 }
@@ -206,19 +222,33 @@ __global__ __launch_bounds__(PIV_THREADS) void deim_block_coeff_kernel(const dou
                                                                        const double* __restrict__ delta,
                                                                        const double* __restrict__ Linv,
                                                                        double* __restrict__ YT) {
-  __shared__ double s_b[1024];
+  constexpr int CG = 4;  // columns per pass over L^-1 (each row of L^-1 is read once per pass)
+  __shared__ double s_b[CG][1024];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  for (int c = 0; c < nb; ++c) {
-    for (int i = tid; i < k0; i += PIV_THREADS) s_b[i] = R[(long)(k0 + c) * ldr + idx[i]];
+  for (int c0 = 0; c0 < nb; c0 += CG) {
     __syncthreads();
-    for (int i = wid; i < k0; i += PIV_THREADS / 64) {
-      double acc = 0.0;
-      for (int j = lane; j <= i; j += 64) acc = fma(Linv[(long)i * m + j], s_b[j], acc);
+    for (int i = tid; i < k0; i += PIV_THREADS) {
+      const long p = idx[i];
 #pragma unroll
-      for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-      if (lane == 0) YT[(long)c * m + i] = acc / delta[i];
+      for (int c = 0; c < CG; ++c) s_b[c][i] = (c0 + c < nb) ? R[(long)(k0 + c0 + c) * ldr + p] : 0.0;
     }
     __syncthreads();
+    for (int i = wid; i < k0; i += PIV_THREADS / 64) {
+      double acc[CG];
+#pragma unroll
+      for (int c = 0; c < CG; ++c) acc[c] = 0.0;
+      for (int j = lane; j <= i; j += 64) {
+        const double l = Linv[(long)i * m + j];
+#pragma unroll
+        for (int c = 0; c < CG; ++c) acc[c] = fma(l, s_b[c][j], acc[c]);
+      }
+      const double di = delta[i];
+#pragma unroll
+      for (int c = 0; c < CG; ++c) {
+        const double sum = rtw::wave_sum(acc[c]);
+        if (lane == 0 && c0 + c < nb) YT[(long)(c0 + c) * m + i] = sum / di;
+      }
+    }
   }
 }
 
