@@ -348,95 +348,96 @@ struct VecParams {
 
 // one wave per eigenvector: inverse iteration on T - lambda I, then back-transformation
 __global__ __launch_bounds__(64) void symeig_vectors_kernel(const VecParams p) {
-  __shared__ double a[NMAX], b[NMAX], c[NMAX], d2[NMAX], z[NMAX];
+  // read-only inputs of the serial sweeps (dd, ee, and y / z alternately) and write-only outputs (ra, ub, ud, lm,
+  // piv) live in DIFFERENT arrays, so the loads of later steps can be issued ahead of the dependent arithmetic:
+  // the chain per step is then a reciprocal and three FMAs instead of an LDS round trip per access
+  __shared__ double dd[NMAX], ee[NMAX + 1], ra[NMAX], ub[NMAX], ud[NMAX], lm[NMAX], z[NMAX], y[NMAX];
   __shared__ unsigned char piv[NMAX];
   const int n = p.n, t = blockIdx.x, lane = threadIdx.x;
   const double lambda = p.lam[t];
   double tnorm = 0.0;
   for (int i = lane; i < n; i += 64) {
-    a[i] = p.d[i] - lambda;
-    b[i] = (i + 1 < n) ? p.e[i] : 0.0;   // superdiagonal
-    c[i] = (i + 1 < n) ? p.e[i] : 0.0;   // subdiagonal (row i+1)
-    d2[i] = 0.0;
+    dd[i] = p.d[i] - lambda;
+    ee[i] = (i + 1 < n) ? p.e[i] : 0.0;   // sub- and superdiagonal (symmetric)
     tnorm = fmax(tnorm, fabs(p.d[i]) + 2.0 * ((i + 1 < n) ? fabs(p.e[i]) : 0.0));
     // deterministic start vector in (-1, 1), different for every eigenvector
     unsigned s = 1664525u * (unsigned)(i + 1 + 7919 * (t + 1)) + 1013904223u;
     s ^= s >> 15; s *= 2246822519u; s ^= s >> 13;
     z[i] = (double)(s & 0xffffff) / 8388608.0 - 1.0;
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) tnorm = fmax(tnorm, __shfl_xor(tnorm, off));
+  if (lane == 0) ee[n] = 0.0;
+  tnorm = rtw::wave_max(tnorm);
   const double tiny = 2.2e-16 * fmax(tnorm, 1e-300);
   __syncthreads();
   if (lane == 0) {
-    // P L U = T - lambda I with partial pivoting (dlagtf recurrences); a[] ends up holding 1/pivot
-    double ak = a[0];
+    // P L U = T - lambda I with partial pivoting (dlagtf recurrences); the running diagonal and superdiagonal
+    // entries stay in registers, ra[] receives 1/pivot
+    double ak = dd[0], bk = ee[0];
+#pragma unroll 4
     for (int k = 0; k + 1 < n; ++k) {
-      const double ck = c[k], bk = b[k], an = a[k + 1];
-      double piv_k, next;
-      if (fabs(ck) <= fabs(ak)) {
-        piv[k] = 0;
-        piv_k = (fabs(ak) < tiny) ? copysign(tiny, ak == 0.0 ? 1.0 : ak) : ak;
-        const double mult = ck * fast_rcp(piv_k);
-        next = fma(-mult, bk, an);
-        c[k] = mult;
-      } else {
-        piv[k] = 1;
-        const double mult = ak * fast_rcp(ck);
-        piv_k = ck;
-        next = fma(-mult, an, bk);
-        if (k + 2 < n) {
-          const double t2 = b[k + 1];
-          d2[k] = t2;
-          b[k + 1] = -mult * t2;
-        }
-        b[k] = an;
-        c[k] = mult;
-      }
-      a[k] = fast_rcp(piv_k);
-      ak = next;
+      const double ck = ee[k], an = dd[k + 1], t2 = ee[k + 1];
+      const bool swap = fabs(ck) > fabs(ak);
+      double pk = swap ? ck : ak;
+      if (!swap && fabs(pk) < tiny) pk = copysign(tiny, pk == 0.0 ? 1.0 : pk);
+      const double rp = fast_rcp(pk);
+      const double mult = (swap ? ak : ck) * rp;
+      ra[k] = rp;
+      lm[k] = mult;
+      piv[k] = swap ? 1 : 0;
+      ub[k] = swap ? an : bk;
+      ud[k] = swap ? t2 : 0.0;
+      const double nd = swap ? fma(-mult, an, bk) : fma(-mult, bk, an);
+      bk = swap ? -mult * t2 : t2;
+      ak = nd;
     }
-    a[n - 1] = fast_rcp((fabs(ak) < tiny) ? copysign(tiny, ak == 0.0 ? 1.0 : ak) : ak);
-    for (int it = 0; it < 3; ++it) {
+    ra[n - 1] = fast_rcp((fabs(ak) < tiny) ? copysign(tiny, ak == 0.0 ? 1.0 : ak) : ak);
+    ub[n - 1] = 0.0;
+    ud[n - 1] = 0.0;
+  }
+  __syncthreads();
+  for (int it = 0; it < 3; ++it) {
+    double zmax = 0.0;
+    if (lane == 0) {
       // forward: y = L^-1 P z (the running entry stays in a register)
       double cur = z[0];
+#pragma unroll 4
       for (int k = 0; k + 1 < n; ++k) {
-        const double nxt = z[k + 1], ck = c[k];
-        if (piv[k]) {
-          z[k] = nxt;
-          cur = fma(-ck, nxt, cur);
-        } else {
-          z[k] = cur;
-          cur = fma(-ck, cur, nxt);
-        }
+        const double nxt = z[k + 1], ck = lm[k];
+        const bool sw = piv[k] != 0;
+        y[k] = sw ? nxt : cur;
+        cur = sw ? fma(-ck, nxt, cur) : fma(-ck, cur, nxt);
       }
-      z[n - 1] = cur;
+      y[n - 1] = cur;
       // backward: U x = y with the reciprocal pivots
-      double z1 = 0.0, z2 = 0.0, zmax = 0.0;
+      double z1 = 0.0, z2 = 0.0;
+#pragma unroll 4
       for (int k = n - 1; k >= 0; --k) {
-        const double zk = fma(-d2[k], z2, fma(-b[k], z1, z[k])) * a[k];
+        const double zk = fma(-ud[k], z2, fma(-ub[k], z1, y[k])) * ra[k];
         z[k] = zk;
         zmax = fmax(zmax, fabs(zk));
         z2 = z1;
         z1 = zk;
       }
-      const double sc = 1.0 / fmax(zmax, 1e-300);
-      for (int k = 0; k < n; ++k) z[k] *= sc;
     }
+    zmax = rtw::first_lane(zmax);
+    __syncthreads();
+    const double sc = 1.0 / fmax(zmax, 1e-300);
+    for (int i = lane; i < n; i += 64) z[i] *= sc;   // all lanes
+    __syncthreads();
   }
-  __syncthreads();
   // unit 2-norm
   double part = 0.0;
   for (int i = lane; i < n; i += 64) part += z[i] * z[i];
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+  part = rtw::wave_sum(part);
   const double inv = 1.0 / sqrt(part);
   for (int i = lane; i < n; i += 64) z[i] *= inv;
   __syncthreads();
-  // x = Q z = H_0 H_1 ... H_{n-3} z : apply the reflectors from the last to the first; the next
-  // reflector's entries are fetched while the current one is applied (lane owns j = lane + 64 q)
+  // x = Q z = H_0 H_1 ... H_{n-3} z : apply the reflectors from the last to the first.  A reflector row comes
+  // from L2 / HBM (~1-2 us away) while applying one takes ~0.1 us, so the rows are fetched RB at a time, one
+  // whole block ahead of the block being applied (lane owns j = lane + 64 q).
   constexpr int PER = NMAX / 64;
-  double zr[PER], vc[PER], vn[PER];
+  constexpr int RBK = 4;
+  double zr[PER], vc[RBK][PER], vn[RBK][PER];
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
     const int j = lane + 64 * q;
@@ -449,21 +450,28 @@ __global__ __launch_bounds__(64) void symeig_vectors_kernel(const VecParams p) {
       dst[q] = (k >= 0 && j > k && j < n) ? p.V[(size_t)k * n + j] : 0.0;
     }
   };
-  fetch(n - 3, vc);
-  for (int k = n - 3; k >= 0; --k) {
-    fetch(k - 1, vn);
-    const double tk = p.tau[k];
-    double dot = 0.0;
 #pragma unroll
-    for (int q = 0; q < PER; ++q) dot = fma(vc[q], zr[q], dot);
+  for (int u = 0; u < RBK; ++u) fetch(n - 3 - u, vc[u]);
+  for (int k0 = n - 3; k0 >= 0; k0 -= RBK) {
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
-    const double sdot = tk * dot;
+    for (int u = 0; u < RBK; ++u) fetch(k0 - RBK - u, vn[u]);
+    double tk[RBK];
 #pragma unroll
-    for (int q = 0; q < PER; ++q) {
-      zr[q] = fma(-sdot, vc[q], zr[q]);
-      vc[q] = vn[q];
+    for (int u = 0; u < RBK; ++u) tk[u] = (k0 - u >= 0) ? p.tau[k0 - u] : 0.0;
+#pragma unroll
+    for (int u = 0; u < RBK; ++u) {  // reflector k0 - u (rows past the start are all zero: no-ops)
+      double dot = 0.0;
+#pragma unroll
+      for (int q = 0; q < PER; ++q) dot = fma(vc[u][q], zr[q], dot);
+      dot = rtw::wave_sum(dot);  // DPP, not ds_bpermute: this sits on a chain of n - 2 dependent reflectors
+      const double sdot = tk[u] * dot;
+#pragma unroll
+      for (int q = 0; q < PER; ++q) zr[q] = fma(-sdot, vc[u][q], zr[q]);
     }
+#pragma unroll
+    for (int u = 0; u < RBK; ++u)
+#pragma unroll
+      for (int q = 0; q < PER; ++q) vc[u][q] = vn[u][q];
   }
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
