@@ -27,6 +27,10 @@ constexpr int LPR = 64;     // lanes per matrix row in the mat-vec / rank-2 upda
 constexpr int TT = 1024;    // threads per workgroup
 static_assert(LPR == 64, "row reductions use the whole-wave DPP sum");
 constexpr int NMAX = 512;
+// inverse iterations per eigenvector: the shifts are eigenvalues to full precision, so the first solve already
+// amplifies the wanted direction by ~1/eps and the second removes what is left of the start vector (dstein also
+// stops after two or three); the caller's Rayleigh-Ritz step cross-checks the result
+constexpr int VEC_ITERS = 2;
 
 struct TriParams {
   const double* G;   // n x n row-major (read only)
@@ -342,9 +346,40 @@ struct VecParams {
   const double* lam;   // descending
   const double* V;     // reflectors
   const double* tau;
+  const double* C;     // 6 cross products v_u . v_w per block of 4 reflectors (symeig_wy_kernel)
   double* W;           // n x k row-major output: column t = eigenvector of lam[t]
   int n, k;
 };
+
+constexpr int RBK = 4;  // reflectors applied together in the back-transformation
+
+// Block b holds the reflectors k0 - u, u = 0..3, k0 = n - 3 - 4 b, applied in that order.  Their mutual inner
+// products do not depend on the vector being transformed, so they are computed once here (one wave per block)
+// and shared by all eigenvectors: C[6 b + {0..5}] = v1.v0, v2.v0, v2.v1, v3.v0, v3.v1, v3.v2.
+__global__ __launch_bounds__(64) void symeig_wy_kernel(const double* __restrict__ V, int n, double* __restrict__ C) {
+  constexpr int PER = NMAX / 64;
+  const int b = blockIdx.x, lane = threadIdx.x, k0 = n - 3 - RBK * b;
+  double v[RBK][PER];
+#pragma unroll
+  for (int u = 0; u < RBK; ++u)
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int k = k0 - u, j = lane + 64 * q;
+      v[u][q] = (k >= 0 && j > k && j < n) ? V[(size_t)k * n + j] : 0.0;
+    }
+  int slot = 0;
+#pragma unroll
+  for (int u = 1; u < RBK; ++u)
+#pragma unroll
+    for (int w = 0; w < u; ++w) {
+      double dot = 0.0;
+#pragma unroll
+      for (int q = 0; q < PER; ++q) dot = fma(v[u][q], v[w][q], dot);
+      dot = rtw::wave_sum(dot);
+      if (lane == 0) C[6 * b + slot] = dot;
+      ++slot;
+    }
+}
 
 // one wave per eigenvector: inverse iteration on T - lambda I, then back-transformation
 __global__ __launch_bounds__(64) void symeig_vectors_kernel(const VecParams p) {
@@ -395,7 +430,7 @@ __global__ __launch_bounds__(64) void symeig_vectors_kernel(const VecParams p) {
     ud[n - 1] = 0.0;
   }
   __syncthreads();
-  for (int it = 0; it < 3; ++it) {
+  for (int it = 0; it < VEC_ITERS; ++it) {
     double zmax = 0.0;
     if (lane == 0) {
       // forward: y = L^-1 P z (the running entry stays in a register)
@@ -436,7 +471,6 @@ __global__ __launch_bounds__(64) void symeig_vectors_kernel(const VecParams p) {
   // from L2 / HBM (~1-2 us away) while applying one takes ~0.1 us, so the rows are fetched RB at a time, one
   // whole block ahead of the block being applied (lane owns j = lane + 64 q).
   constexpr int PER = NMAX / 64;
-  constexpr int RBK = 4;
   double zr[PER], vc[RBK][PER], vn[RBK][PER];
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
@@ -452,22 +486,35 @@ __global__ __launch_bounds__(64) void symeig_vectors_kernel(const VecParams p) {
   };
 #pragma unroll
   for (int u = 0; u < RBK; ++u) fetch(n - 3 - u, vc[u]);
-  for (int k0 = n - 3; k0 >= 0; k0 -= RBK) {
+  int blk = 0;
+  for (int k0 = n - 3; k0 >= 0; k0 -= RBK, ++blk) {
 #pragma unroll
     for (int u = 0; u < RBK; ++u) fetch(k0 - RBK - u, vn[u]);
-    double tk[RBK];
+    double tk[RBK], cc[6];
 #pragma unroll
     for (int u = 0; u < RBK; ++u) tk[u] = (k0 - u >= 0) ? p.tau[k0 - u] : 0.0;
 #pragma unroll
-    for (int u = 0; u < RBK; ++u) {  // reflector k0 - u (rows past the start are all zero: no-ops)
+    for (int q = 0; q < 6; ++q) cc[q] = p.C[6 * blk + q];
+    // the four reflectors k0, k0-1, k0-2, k0-3 at once: a_u = v_u . z for the incoming z (four independent
+    // reductions), then s_u = tau_u (a_u - sum_{w<u} (v_u . v_w) s_w) and z -= sum_u s_u v_u.  One reduction round
+    // on the serial chain per block instead of one per reflector.
+    double a[RBK];
+#pragma unroll
+    for (int u = 0; u < RBK; ++u) {
       double dot = 0.0;
 #pragma unroll
       for (int q = 0; q < PER; ++q) dot = fma(vc[u][q], zr[q], dot);
-      dot = rtw::wave_sum(dot);  // DPP, not ds_bpermute: this sits on a chain of n - 2 dependent reflectors
-      const double sdot = tk[u] * dot;
-#pragma unroll
-      for (int q = 0; q < PER; ++q) zr[q] = fma(-sdot, vc[u][q], zr[q]);
+      a[u] = dot;
     }
+#pragma unroll
+    for (int u = 0; u < RBK; ++u) a[u] = rtw::wave_sum(a[u]);
+    const double s0 = tk[0] * a[0];
+    const double s1 = tk[1] * (a[1] - cc[0] * s0);
+    const double s2 = tk[2] * (a[2] - cc[1] * s0 - cc[2] * s1);
+    const double s3 = tk[3] * (a[3] - cc[3] * s0 - cc[4] * s1 - cc[5] * s2);
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+      zr[q] = fma(-s3, vc[3][q], fma(-s2, vc[2][q], fma(-s1, vc[1][q], fma(-s0, vc[0][q], zr[q]))));
 #pragma unroll
     for (int u = 0; u < RBK; ++u)
 #pragma unroll
@@ -544,6 +591,13 @@ extern "C" int rt_sym_eig_vectors(rt_ctx* ctx, int64_t n, int64_t k, const doubl
   VecParams vp;
   vp.d = g_state.tp.d; vp.e = g_state.tp.e; vp.lam = lam; vp.V = g_state.tp.V; vp.tau = g_state.tp.tau;
   vp.W = W; vp.n = (int)n; vp.k = (int)k;
+  const int nblk = (int)((n - 2 + RBK - 1) / RBK);
+  void* cbuf = nullptr;
+  int rc = rt_scratch(ctx, sizeof(double) * 6 * (size_t)nblk, &cbuf);  // leaf arena: free between the two calls
+  if (rc != RT_OK) return rc;
+  vp.C = static_cast<const double*>(cbuf);
+  hipLaunchKernelGGL(symeig_wy_kernel, dim3((unsigned)nblk), dim3(64), 0, ctx->stream, vp.V, (int)n,
+                     static_cast<double*>(cbuf));
   hipLaunchKernelGGL(symeig_vectors_kernel, dim3((unsigned)k), dim3(64), 0, ctx->stream, vp);
   RT_HIP_CHECK(ctx, hipGetLastError());
   return RT_OK;
