@@ -270,17 +270,20 @@ __global__ void symeig_init_kernel(int* flags, double* tau, int n) {
   for (int i = threadIdx.x; i < n; i += blockDim.x) tau[i] = 0.0;
 }
 
-// lam[j] = j-th LARGEST eigenvalue of T.  One single-wave workgroup per eigenvalue, so the n waves spread
-// over all CUs (about one wave per two SIMDs: latency-bound), and each lane runs NS independent Sturm
-// recurrences to fill the rcp/fma latency: 64 NS + 1 sections per pass, 7 passes (257^7 > 2^53).
-__global__ __launch_bounds__(64) void symeig_bisect_kernel(const double* __restrict__ d, const double* __restrict__ e,
-                                                           int n, double* __restrict__ lam, const int* flags,
-                                                           int* status) {
+// lam[j] = j-th LARGEST eigenvalue of T by Sturm-count multisection, 257 sections per pass, 7 passes
+// (257^7 > 2^53).  The loop is instruction-issue bound (one wave per SIMD, ~9 FP64 instructions per shift and row),
+// so an eigenvalue is shared by TWO waves with 2 shifts per lane, and a workgroup is four waves = two
+// eigenvalues: its waves occupy the four SIMDs of one CU, n/2 workgroups put one wave on every SIMD of the chip.
+constexpr int BIS_NS = 2;  // shifts per lane
+__global__ __launch_bounds__(256) void symeig_bisect_kernel(const double* __restrict__ d, const double* __restrict__ e,
+                                                            int n, double* __restrict__ lam, const int* flags,
+                                                            int* status) {
   if (status && blockIdx.x == 0 && threadIdx.x == 0) *status = flags[3];
   __shared__ double sd[NMAX], se2[NMAX];
-  const int lane = threadIdx.x;
+  __shared__ int s_first[2][4];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, half = wid & 1;
   double glo = 1e300, ghi = -1e300, emax = 0.0;
-  for (int i = lane; i < n; i += 64) {
+  for (int i = lane; i < n; i += 64) {  // every wave scans all of T (same values): its bounds are complete
     const double di = d[i], ei = (i + 1 < n) ? e[i] : 0.0, el = (i > 0) ? fabs(e[i - 1]) : 0.0;
     sd[i] = di;
     se2[i] = ei * ei;
@@ -288,56 +291,48 @@ __global__ __launch_bounds__(64) void symeig_bisect_kernel(const double* __restr
     ghi = fmax(ghi, di + el + fabs(ei));
     emax = fmax(emax, ei * ei);
   }
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {
-    glo = fmin(glo, __shfl_xor(glo, off));
-    ghi = fmax(ghi, __shfl_xor(ghi, off));
-    emax = fmax(emax, __shfl_xor(emax, off));
-  }
+  glo = rtw::wave_min(glo);
+  ghi = rtw::wave_max(ghi);
+  emax = rtw::wave_max(emax);
   __syncthreads();
   const double tn = fmax(fabs(glo), fabs(ghi));
   double lo = glo - 2.2e-16 * tn * n - 1e-300, hi = ghi + 2.2e-16 * tn * n + 1e-300;
   const double pivmin = 2.2250738585072014e-308 * fmax(1.0, emax);
-  const int j = blockIdx.x;      // descending index
+  const int j = min(2 * (int)blockIdx.x + (wid >> 1), n - 1);  // descending index (an odd n repeats the last one)
   const int want = n - j;        // ascending rank (1-based): smallest x with count(x) >= want
-  constexpr int NS = 4;
-  constexpr int NSEC = 64 * NS + 1;
+  constexpr int NSH = 128 * BIS_NS;  // shifts per pass
+  constexpr int NSEC = NSH + 1;
   for (int pass = 0; pass < 7; ++pass) {
     const double h = (hi - lo) / NSEC;
-    const double x0 = lo + h * (NS * lane + 1), x1 = x0 + h, x2 = x0 + 2 * h, x3 = x0 + 3 * h;
-    double q0 = sd[0] - x0, q1 = sd[0] - x1, q2 = sd[0] - x2, q3 = sd[0] - x3;
+    const int s0 = BIS_NS * (64 * half + lane);
+    const double x0 = lo + h * (s0 + 1), x1 = x0 + h;
+    double q0 = sd[0] - x0, q1 = sd[0] - x1;
     if (fabs(q0) < pivmin) q0 = -pivmin;
     if (fabs(q1) < pivmin) q1 = -pivmin;
-    if (fabs(q2) < pivmin) q2 = -pivmin;
-    if (fabs(q3) < pivmin) q3 = -pivmin;
-    int c0 = (q0 < 0.0), c1 = (q1 < 0.0), c2 = (q2 < 0.0), c3 = (q3 < 0.0);
+    int c0 = (q0 < 0.0), c1 = (q1 < 0.0);
     for (int i = 1; i < n; ++i) {
       const double di = sd[i], ei = se2[i - 1];
       q0 = fma(-ei, fast_rcp(q0), di - x0);
       q1 = fma(-ei, fast_rcp(q1), di - x1);
-      q2 = fma(-ei, fast_rcp(q2), di - x2);
-      q3 = fma(-ei, fast_rcp(q3), di - x3);
       if (fabs(q0) < pivmin) q0 = -pivmin;
       if (fabs(q1) < pivmin) q1 = -pivmin;
-      if (fabs(q2) < pivmin) q2 = -pivmin;
-      if (fabs(q3) < pivmin) q3 = -pivmin;
-      c0 += (q0 < 0.0); c1 += (q1 < 0.0); c2 += (q2 < 0.0); c3 += (q3 < 0.0);
+      c0 += (q0 < 0.0); c1 += (q1 < 0.0);
     }
-    int first = 64 * NS;  // index of the first shift whose count reaches `want` (none: 64 NS)
-    if (c3 >= want) first = NS * lane + 3;
-    if (c2 >= want) first = NS * lane + 2;
-    if (c1 >= want) first = NS * lane + 1;
-    if (c0 >= want) first = NS * lane;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) first = min(first, __shfl_xor(first, off));
-    if (first == 64 * NS) {
-      lo = lo + h * (64 * NS);
+    int first = NSH;  // index of the first shift whose count reaches `want` (none: NSH)
+    if (c1 >= want) first = s0 + 1;
+    if (c0 >= want) first = s0;
+    first = rtw::wave_min_i32(first);
+    if (lane == 0) s_first[pass & 1][wid] = first;
+    __syncthreads();  // this parity's slots are rewritten two barriers later
+    first = min(s_first[pass & 1][wid & 2], s_first[pass & 1][(wid & 2) + 1]);
+    if (first == NSH) {
+      lo = lo + h * NSH;
     } else {
       hi = lo + h * (first + 1);
       lo = lo + h * first;
     }
   }
-  if (lane == 0) lam[j] = 0.5 * (lo + hi);
+  if (lane == 0 && half == 0) lam[j] = 0.5 * (lo + hi);
 }
 
 struct VecParams {
@@ -574,7 +569,7 @@ extern "C" int rt_sym_eig_values(rt_ctx* ctx, const double* G, int64_t n, double
   }
   hipLaunchKernelGGL(symeig_tridiag_kernel, dim3(TW), dim3(TT), lds, st, tp);
   RT_HIP_CHECK(ctx, hipGetLastError());
-  hipLaunchKernelGGL(symeig_bisect_kernel, dim3((unsigned)n), dim3(64), 0, st, tp.d, tp.e, (int)n, lam,
+  hipLaunchKernelGGL(symeig_bisect_kernel, dim3((unsigned)((n + 1) / 2)), dim3(256), 0, st, tp.d, tp.e, (int)n, lam,
                      tp.flags, status);
   RT_HIP_CHECK(ctx, hipGetLastError());
   g_state.tp = tp; g_state.n = n; g_state.base = base;

@@ -72,6 +72,16 @@ __device__ __forceinline__ double wave_min(double x) {
   return read_lane(x, 63);
 }
 
+__device__ __forceinline__ int wave_min_i32(int x) {
+  x = min(x, dpp_keep_i32<0xb1>(x));
+  x = min(x, dpp_keep_i32<0x4e>(x));
+  x = min(x, dpp_keep_i32<0x114>(x));
+  x = min(x, dpp_keep_i32<0x118>(x));
+  x = min(x, dpp_keep_i32<0x142, 0xa>(x));
+  x = min(x, dpp_keep_i32<0x143, 0xc>(x));
+  return __builtin_amdgcn_readlane(x, 63);
+}
+
 // argmax over the wave with the order (value descending, index ascending); wave-uniform result
 template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
 __device__ __forceinline__ void argmax_step(double& v, int& i) {
