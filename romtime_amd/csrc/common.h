@@ -19,6 +19,12 @@ struct rt_ctx {
   bool profile = false;             // bracket the main GEMM kernel with events (rt_ctx_set_profile)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool ev_valid = false;
+  // state handed from rt_sym_eig_values to rt_sym_eig_vectors (pointers into the composite arena)
+  struct {
+    const double *d = nullptr, *e = nullptr, *V = nullptr, *tau = nullptr;
+    int64_t n = 0;
+    void* base = nullptr;
+  } eig;
 };
 
 #define RT_HIP_CHECK(ctx, expr)                                                              \

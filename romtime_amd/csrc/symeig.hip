@@ -526,15 +526,6 @@ __global__ __launch_bounds__(64) void symeig_vectors_kernel(const VecParams p) {
 
 }  // namespace
 
-namespace {
-struct EigState {  // carved from the ctx's composite arena by rt_sym_eig_values, reused by rt_sym_eig_vectors
-  TriParams tp;
-  int64_t n = 0;
-  void* base = nullptr;
-};
-EigState g_state;  // one per process is enough: a ctx serialises its calls, and the pair is called back to back
-}  // namespace
-
 extern "C" int rt_sym_eig_values(rt_ctx* ctx, const double* G, int64_t n, double* lam, int* status) {
   if (!ctx) return RT_ERR_ARG;
   RT_ARG_CHECK(ctx, G && lam && n >= 3);
@@ -572,19 +563,19 @@ extern "C" int rt_sym_eig_values(rt_ctx* ctx, const double* G, int64_t n, double
   hipLaunchKernelGGL(symeig_bisect_kernel, dim3((unsigned)((n + 1) / 2)), dim3(256), 0, st, tp.d, tp.e, (int)n, lam,
                      tp.flags, status);
   RT_HIP_CHECK(ctx, hipGetLastError());
-  g_state.tp = tp; g_state.n = n; g_state.base = base;
+  ctx->eig.d = tp.d; ctx->eig.e = tp.e; ctx->eig.V = tp.V; ctx->eig.tau = tp.tau; ctx->eig.n = n; ctx->eig.base = base;
   return RT_OK;
 }
 
 extern "C" int rt_sym_eig_vectors(rt_ctx* ctx, int64_t n, int64_t k, const double* lam, double* W) {
   if (!ctx) return RT_ERR_ARG;
   RT_ARG_CHECK(ctx, lam && W && k >= 1 && k <= n);
-  if (g_state.n != n || g_state.base == nullptr || g_state.base != ctx->scratch2) {
+  if (ctx->eig.n != n || ctx->eig.base == nullptr || ctx->eig.base != ctx->scratch2) {
     ctx->err = "rt_sym_eig_vectors: must directly follow rt_sym_eig_values on the same ctx and matrix";
     return RT_ERR_ARG;
   }
   VecParams vp;
-  vp.d = g_state.tp.d; vp.e = g_state.tp.e; vp.lam = lam; vp.V = g_state.tp.V; vp.tau = g_state.tp.tau;
+  vp.d = ctx->eig.d; vp.e = ctx->eig.e; vp.lam = lam; vp.V = ctx->eig.V; vp.tau = ctx->eig.tau;
   vp.W = W; vp.n = (int)n; vp.k = (int)k;
   const int nblk = (int)((n - 2 + RBK - 1) / RBK);
   void* cbuf = nullptr;
