@@ -270,6 +270,10 @@ int rt_gemm_nn(rt_ctx* ctx, const double* X, int64_t ldx, int x_layout, const do
   RT_ARG_CHECK(ctx, (x_layout == RT_ROW_MAJOR || x_layout == RT_COL_MAJOR) &&
                         (y_layout == RT_ROW_MAJOR || y_layout == RT_COL_MAJOR));
   RT_ARG_CHECK(ctx, ldx >= (x_layout == RT_ROW_MAJOR ? n : N) && ldy >= (y_layout == RT_ROW_MAJOR ? k : N));
+  if (x_layout == RT_ROW_MAJOR && y_layout == RT_ROW_MAJOR) {  // tall X, few columns out: the streaming kernel
+    const int rc = rt_tallskinny(ctx, X, ldx, T, ldt, N, n, k, Y, ldy);
+    if (rc != RT_ERR_UNSUPPORTED) return rc;
+  }
   // contraction over the n columns of X: A(c, i) = X[i][c]
   const int64_t a_ks = (x_layout == RT_ROW_MAJOR) ? 1 : ldx, a_ms = (x_layout == RT_ROW_MAJOR) ? ldx : 1;
   const int64_t c_rs = (y_layout == RT_ROW_MAJOR) ? ldy : 1, c_cs = (y_layout == RT_ROW_MAJOR) ? 1 : ldy;

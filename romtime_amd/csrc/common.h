@@ -61,6 +61,10 @@ int rt_gemm_strided(rt_ctx* ctx, const double* A, int64_t a_ks, int64_t a_ms, co
 // Specialised Gram kernel (gram_mfma.hip); RT_ERR_UNSUPPORTED means "use rt_gemm_strided".
 int rt_gram128(rt_ctx* ctx, const double* X, int64_t ks, int64_t ms, int64_t K, int64_t n, double* G);
 
+// Tall-skinny Y = X T for row-major X, k <= 64 (tallskinny.hip); RT_ERR_UNSUPPORTED outside its range.
+int rt_tallskinny(rt_ctx* ctx, const double* X, int64_t ldx, const double* T, int64_t ldt, int64_t N, int64_t n,
+                  int64_t k, double* Y, int64_t ldy);
+
 // Newton-Schulz inverse tracking solve for the online sweep (solve.hip); RT_ERR_UNSUPPORTED for r > 80.
 struct rt_newton_rhs {  // b = M_N (c0 u^n + c1 u^{n-1}) + dt Zf^T F_rhs, per system; MN == nullptr: rhs is given
   const double* MN;    // B x r x r

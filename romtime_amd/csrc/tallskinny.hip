@@ -1,0 +1,154 @@
+// Tall-skinny product  Y (N x k) = X (N x n, row-major) T (n x k),  k <= 64: the POD back-projection
+// U_r = X W (pod.py:38 folded into the Gram route, SURVEY 8d "POD pass 2") and the lift u_h = V u_N.
+//
+// 8 N (n + k) bytes for 2 N n k flops: at k = 40 (three 16-wide MFMA column tiles) the matrix-core time is
+// within 15 % of the HBM time, so the kernel is built to overlap the two as well as possible rather than for
+// either alone: a workgroup takes 64 rows and walks the contraction in stages of 32 columns (256 contiguous
+// bytes per row), X and T stages go HBM -> registers -> LDS (next stage in flight while the current one is
+// multiplied), 4 waves x 16 rows, each wave all ceil(k/16) column tiles; 29 KB of LDS and <= 128 VGPRs leave room
+// for four workgroups per CU.  Measured 4.1 TB/s at 1e6 x 512 -> 40 (generic skinny tile: 3.8; 64-column stages
+// with two workgroups per CU: 3.8).
+#include "common.h"
+
+typedef double d2 __attribute__((ext_vector_type(2)));
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int TS_THREADS = 256;
+constexpr int TS_BM = 64;      // rows per workgroup
+constexpr int TS_KS = 32;      // contraction columns per stage
+constexpr int TS_SA = 34;      // LDS stride of the X stage ([row][k]): 2 SA == 4 (mod 8) -> the 16 rows of an
+                               // A-operand read fall in distinct banks
+constexpr int TS_XL = TS_BM * TS_KS / 2 / TS_THREADS;  // d2 loads of X per thread and stage
+
+struct TsParams {
+  const double* X;
+  const double* T;
+  double* Y;
+  long N, ldx, ldt, ldy;
+  int n, k;
+};
+
+template <int NT>
+__global__ __launch_bounds__(TS_THREADS, 4) void tallskinny_kernel(const TsParams p) {
+  constexpr int KP = 16 * NT;                                 // padded output width
+  constexpr int TL = (TS_KS * KP / 2 + TS_THREADS - 1) / TS_THREADS;  // d2 loads of T per thread and stage
+  __shared__ __attribute__((aligned(16))) double sA[TS_BM * TS_SA];
+  __shared__ __attribute__((aligned(16))) double sT[TS_KS * KP];
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long row0 = (long)blockIdx.x * TS_BM;
+  const bool xvec = ((p.ldx & 1) == 0) && ((reinterpret_cast<size_t>(p.X) & 15) == 0);
+  const bool tvec = ((p.ldt & 1) == 0) && ((reinterpret_cast<size_t>(p.T) & 15) == 0);
+
+  d4 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
+
+  d2 xr[TS_XL], tr[TL];
+  auto fetch = [&](int c0) {  // stage of contraction columns c0 .. c0 + TS_KS - 1 into registers
+#pragma unroll
+    for (int i = 0; i < TS_XL; ++i) {
+      const int q = tid + TS_THREADS * i, r = q / (TS_KS / 2), c = c0 + 2 * (q % (TS_KS / 2));
+      const long row = row0 + r;
+      d2 v{0.0, 0.0};
+      if (row < p.N) {
+        const double* src = p.X + row * p.ldx + c;
+        if (xvec && c + 1 < p.n) {
+          v = *reinterpret_cast<const d2*>(src);
+        } else {
+          if (c < p.n) v.x = src[0];
+          if (c + 1 < p.n) v.y = src[1];
+        }
+      }
+      xr[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < TL; ++i) {
+      const int q = tid + TS_THREADS * i, kk = q / (KP / 2), j = 2 * (q % (KP / 2));
+      d2 v{0.0, 0.0};
+      if (kk < TS_KS && c0 + kk < p.n) {
+        const double* src = p.T + (long)(c0 + kk) * p.ldt + j;
+        if (tvec && j + 1 < p.k) {
+          v = *reinterpret_cast<const d2*>(src);
+        } else {
+          if (j < p.k) v.x = src[0];
+          if (j + 1 < p.k) v.y = src[1];
+        }
+      }
+      tr[i] = v;
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < TS_XL; ++i) {
+      const int q = tid + TS_THREADS * i, r = q / (TS_KS / 2), c = 2 * (q % (TS_KS / 2));
+      *reinterpret_cast<d2*>(&sA[r * TS_SA + c]) = xr[i];
+    }
+#pragma unroll
+    for (int i = 0; i < TL; ++i) {
+      const int q = tid + TS_THREADS * i, kk = q / (KP / 2), j = 2 * (q % (KP / 2));
+      if (kk < TS_KS) *reinterpret_cast<d2*>(&sT[kk * KP + j]) = tr[i];
+    }
+  };
+
+  fetch(0);
+  commit();
+  __syncthreads();
+  const double* fa = sA + (16 * wid + l15) * TS_SA + l4;  // A operand: row 16 w + l15, k = 4 k4 + l4
+  const double* fb = sT + l4 * KP + l15;                   // B operand: k = 4 k4 + l4, column 16 j + l15
+  for (int c0 = 0; c0 < p.n; c0 += TS_KS) {
+    const bool more = c0 + TS_KS < p.n;
+    if (more) fetch(c0 + TS_KS);
+#pragma unroll
+    for (int k4 = 0; k4 < TS_KS / 4; ++k4) {
+      const double a = fa[4 * k4];
+#pragma unroll
+      for (int j = 0; j < NT; ++j)
+        acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fb[4 * k4 * KP + 16 * j], acc[j], 0, 0, 0);
+    }
+    __syncthreads();
+    if (more) commit();
+    __syncthreads();
+  }
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const long row = row0 + 16 * wid + l4 + 4 * c;
+      const int col = 16 * j + l15;
+      if (row < p.N && col < p.k) p.Y[row * p.ldy + col] = acc[j][c];
+    }
+}
+
+}  // namespace
+
+// RT_ERR_UNSUPPORTED: shape outside this kernel's range (the caller uses the generic GEMM).
+int rt_tallskinny(rt_ctx* ctx, const double* X, int64_t ldx, const double* T, int64_t ldt, int64_t N, int64_t n,
+                  int64_t k, double* Y, int64_t ldy) {
+  if (k > 64 || n < 2 * TS_KS || N < 64L * ctx->num_cus) return RT_ERR_UNSUPPORTED;
+  TsParams p{X, T, Y, (long)N, (long)ldx, (long)ldt, (long)ldy, (int)n, (int)k};
+  const unsigned grid = (unsigned)((N + TS_BM - 1) / TS_BM);
+  const int nt = (int)((k + 15) / 16);
+  if (ctx->profile) {
+    if (!ctx->ev0) {
+      RT_HIP_CHECK(ctx, hipEventCreate(&ctx->ev0));
+      RT_HIP_CHECK(ctx, hipEventCreate(&ctx->ev1));
+    }
+    RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  }
+  switch (nt) {
+    case 1: hipLaunchKernelGGL(tallskinny_kernel<1>, dim3(grid), dim3(TS_THREADS), 0, ctx->stream, p); break;
+    case 2: hipLaunchKernelGGL(tallskinny_kernel<2>, dim3(grid), dim3(TS_THREADS), 0, ctx->stream, p); break;
+    case 3: hipLaunchKernelGGL(tallskinny_kernel<3>, dim3(grid), dim3(TS_THREADS), 0, ctx->stream, p); break;
+    default: hipLaunchKernelGGL(tallskinny_kernel<4>, dim3(grid), dim3(TS_THREADS), 0, ctx->stream, p); break;
+  }
+  RT_HIP_CHECK(ctx, hipGetLastError());
+  if (ctx->profile) {
+    RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->ev_valid = true;
+  }
+  ctx->last_grid = grid; ctx->last_splits = 1; ctx->last_tile = TS_BM * 1000 + 16 * nt;
+  return RT_OK;
+}
