@@ -175,6 +175,12 @@ int rt_hrom_bdf_sweep(rt_ctx* ctx, const rt_hsweep_desc* desc, double* uN_out);
  * status (device int, may be NULL): 0, or 1 if the inter-workgroup hand-off timed out (results
  * invalid).  Replaces the eigenvalue half of LAPACK's work inside scipy.linalg.svd (pod.py:38). */
 int rt_sym_eig_values(rt_ctx* ctx, const double* G, int64_t n, double* lam, int* status);
+/* The same, but only the eigenvalues with descending index in [first, first + count) are searched and written
+ * (lam[first .. first+count)); the tridiagonalisation is complete either way.  For a row-sharded POD every rank
+ * holds the same G after the all-reduce: the ranks split the multisection (and the eigenvectors, by passing
+ * lam + first and their share of k to rt_sym_eig_vectors) and all-gather the pieces. */
+int rt_sym_eig_values_part(rt_ctx* ctx, const double* G, int64_t n, int64_t first, int64_t count, double* lam,
+                           int* status);
 /* Eigenvectors of the k LARGEST eigenvalues by inverse iteration on the tridiagonal form and
  * back-transformation; must directly follow rt_sym_eig_values on the same ctx (it reuses the
  * reflectors kept in the ctx's workspace).  W: n x k row-major, column t pairs with lam[t]. */

@@ -45,6 +45,7 @@ SIGNATURES = {
     "rt_rom_bdf_sweep": (_int, [_p, _p, _p]),
     "rt_hrom_bdf_sweep": (_int, [_p, _p, _p]),
     "rt_sym_eig_values": (_int, [_p, _p, _i64, _p, _p]),
+    "rt_sym_eig_values_part": (_int, [_p, _p, _i64, _i64, _i64, _p, _p]),
     "rt_sym_eig_vectors": (_int, [_p, _i64, _i64, _p, _p]),
     "rt_host_jacobi_eigh": (_int, [_p, _i64, _p, _p, _int, C.POINTER(_int)]),
     "rt_bench_mfma_f64": (_int, [_p, _int, C.POINTER(C.c_double)]),

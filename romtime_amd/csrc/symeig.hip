@@ -276,8 +276,8 @@ __global__ void symeig_init_kernel(int* flags, double* tau, int n) {
 // eigenvalues: its waves occupy the four SIMDs of one CU, n/2 workgroups put one wave on every SIMD of the chip.
 constexpr int BIS_NS = 2;  // shifts per lane
 __global__ __launch_bounds__(256) void symeig_bisect_kernel(const double* __restrict__ d, const double* __restrict__ e,
-                                                            int n, double* __restrict__ lam, const int* flags,
-                                                            int* status) {
+                                                            int n, int first, int count, double* __restrict__ lam,
+                                                            const int* flags, int* status) {
   if (status && blockIdx.x == 0 && threadIdx.x == 0) *status = flags[3];
   __shared__ double sd[NMAX], se2[NMAX];
   __shared__ int s_first[2][4];
@@ -298,7 +298,8 @@ __global__ __launch_bounds__(256) void symeig_bisect_kernel(const double* __rest
   const double tn = fmax(fabs(glo), fabs(ghi));
   double lo = glo - 2.2e-16 * tn * n - 1e-300, hi = ghi + 2.2e-16 * tn * n + 1e-300;
   const double pivmin = 2.2250738585072014e-308 * fmax(1.0, emax);
-  const int j = min(2 * (int)blockIdx.x + (wid >> 1), n - 1);  // descending index (an odd n repeats the last one)
+  // descending index, inside [first, first + count) (an odd count repeats the last one)
+  const int j = first + min(2 * (int)blockIdx.x + (wid >> 1), count - 1);
   const int want = n - j;        // ascending rank (1-based): smallest x with count(x) >= want
   constexpr int NSH = 128 * BIS_NS;  // shifts per pass
   constexpr int NSEC = NSH + 1;
@@ -527,8 +528,13 @@ __global__ __launch_bounds__(64) void symeig_vectors_kernel(const VecParams p) {
 }  // namespace
 
 extern "C" int rt_sym_eig_values(rt_ctx* ctx, const double* G, int64_t n, double* lam, int* status) {
+  return rt_sym_eig_values_part(ctx, G, n, 0, n, lam, status);
+}
+
+extern "C" int rt_sym_eig_values_part(rt_ctx* ctx, const double* G, int64_t n, int64_t first, int64_t count, double* lam,
+                                      int* status) {
   if (!ctx) return RT_ERR_ARG;
-  RT_ARG_CHECK(ctx, G && lam && n >= 3);
+  RT_ARG_CHECK(ctx, G && lam && n >= 3 && first >= 0 && count >= 1 && first + count <= n);
   if (n > NMAX) {
     ctx->err = "rt_sym_eig_values: n > 512 not supported (the matrix must fit the LDS of 16 CUs)";
     return RT_ERR_UNSUPPORTED;
@@ -560,8 +566,8 @@ extern "C" int rt_sym_eig_values(rt_ctx* ctx, const double* G, int64_t n, double
   }
   hipLaunchKernelGGL(symeig_tridiag_kernel, dim3(TW), dim3(TT), lds, st, tp);
   RT_HIP_CHECK(ctx, hipGetLastError());
-  hipLaunchKernelGGL(symeig_bisect_kernel, dim3((unsigned)((n + 1) / 2)), dim3(256), 0, st, tp.d, tp.e, (int)n, lam,
-                     tp.flags, status);
+  hipLaunchKernelGGL(symeig_bisect_kernel, dim3((unsigned)((count + 1) / 2)), dim3(256), 0, st, tp.d, tp.e, (int)n,
+                     (int)first, (int)count, lam, tp.flags, status);
   RT_HIP_CHECK(ctx, hipGetLastError());
   ctx->eig.d = tp.d; ctx->eig.e = tp.e; ctx->eig.V = tp.V; ctx->eig.tau = tp.tau; ctx->eig.n = n; ctx->eig.base = base;
   return RT_OK;

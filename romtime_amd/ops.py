@@ -178,23 +178,27 @@ def dense_solve(K: torch.Tensor, b: torch.Tensor):
     return (bw[0] if single else bw), info
 
 
-def sym_eig_values(G: torch.Tensor):
-    """All eigenvalues (descending, device) of the symmetric n x n G; (lam, status). rt_sym_eig_values."""
+def sym_eig_values(G: torch.Tensor, first: int = 0, count: int | None = None):
+    """Eigenvalues (descending, device) of the symmetric n x n G; (lam, status).  With ``first`` / ``count`` only
+    lam[first:first+count] is computed (the rest of ``lam`` is left unset).  rt_sym_eig_values(_part)."""
     ctx = Context.current()
     n = G.shape[0]
     assert G.is_contiguous() and G.shape == (n, n)
+    count = n - first if count is None else count
     lam = torch.empty(n, dtype=torch.float64, device=G.device)
     status = torch.zeros(1, dtype=torch.int32, device=G.device)
-    ctx.check(ctx.lib.rt_sym_eig_values(ctx.handle, _ptr(G), n, _ptr(lam), _ptr(status)), "rt_sym_eig_values")
+    ctx.check(ctx.lib.rt_sym_eig_values_part(ctx.handle, _ptr(G), n, first, count, _ptr(lam), _ptr(status)),
+              "rt_sym_eig_values_part")
     return lam, status
 
 
-def sym_eig_vectors(lam: torch.Tensor, k: int) -> torch.Tensor:
-    """Eigenvectors (n x k) of the k largest eigenvalues; directly after sym_eig_values. rt_sym_eig_vectors."""
+def sym_eig_vectors(lam: torch.Tensor, k: int, first: int = 0) -> torch.Tensor:
+    """Eigenvectors (n x k) of lam[first:first+k] (descending eigenvalues); directly after sym_eig_values.
+    rt_sym_eig_vectors."""
     ctx = Context.current()
     n = lam.numel()
     W = torch.empty((n, k), dtype=torch.float64, device=lam.device)
-    ctx.check(ctx.lib.rt_sym_eig_vectors(ctx.handle, n, k, _ptr(lam), _ptr(W)), "rt_sym_eig_vectors")
+    ctx.check(ctx.lib.rt_sym_eig_vectors(ctx.handle, n, k, _ptr(lam[first:]), _ptr(W)), "rt_sym_eig_vectors")
     return W
 
 

@@ -120,11 +120,24 @@ class _SmallEig:
     (rt_sym_eig_values / rt_sym_eig_vectors, Rayleigh-Ritz polish on G when kept eigenvalues are
     closer than RR_GAP * lam_1); other sizes use host LAPACK."""
 
-    def __init__(self, G: torch.Tensor, extra=()):
+    def __init__(self, G: torch.Tensor, extra=(), group=None):
         self.G, self.n = G, G.shape[0]
         self.on_device = bool(G.is_cuda and DEVICE_EIG and 3 <= self.n <= DEVICE_EIG_MAX_N)
+        self.group = group if (group is not None and self.on_device and _world(group) > 1) else None
         if self.on_device:
-            self.lam_d, status = ops.sym_eig_values(G)
+            if self.group is None:
+                self.lam_d, status = ops.sym_eig_values(G)
+            else:
+                # every rank holds the same G: the tridiagonalisation is replicated (bit-identical), the
+                # multisection is split over the ranks and the pieces are all-gathered
+                first, cnt = _share(self.n, self.group)
+                part, status = ops.sym_eig_values(G, first, cnt)
+                pieces = _allgather(torch.cat([part[first:first + cnt], status.to(torch.float64)]), self.group)
+                self.lam_d = torch.empty(self.n, dtype=torch.float64, device=G.device)
+                for r, piece in enumerate(pieces):
+                    f, _ = _share(self.n, self.group, rank=r)
+                    self.lam_d[f:f + cnt] = piece[:cnt]
+                status = torch.stack([piece[cnt] for piece in pieces]).max().reshape(1)
             head = torch.cat([self.lam_d, status.to(torch.float64)] + [e.to(torch.float64).reshape(-1) for e in extra])
             head = head.cpu().numpy()  # the one device->host transfer of the step
             self.lam, self.extra = head[: self.n], head[self.n + 1:]
@@ -143,7 +156,15 @@ class _SmallEig:
         n, lam = self.n, self.lam
         if not self.on_device:
             return ops.to_device(np.ascontiguousarray(self.W[:, :k]), self.G.device)
-        Z = ops.sym_eig_vectors(self.lam_d, k)
+        if self.group is None:
+            Z = ops.sym_eig_vectors(self.lam_d, k)
+        else:  # each rank back-transforms its share of the k vectors
+            first, cnt = _share(k, self.group)
+            pieces = _allgather(ops.sym_eig_vectors(self.lam_d, cnt, first=first), self.group)
+            Z = torch.empty((n, k), dtype=torch.float64, device=self.G.device)
+            for r, piece in enumerate(pieces):
+                f, _ = _share(k, self.group, rank=r)
+                Z[:, f:f + cnt] = piece
         # inverse iteration resolves an eigenvector to ~eps ||G|| / gap: with every gap among the kept
         # eigenvalues (and to the first discarded one) above RR_GAP * lam_1 that is <= 2e-12 and the
         # vectors are used as they are; closer eigenvalues get a k x k Rayleigh-Ritz step on G
@@ -159,6 +180,31 @@ class _SmallEig:
         if np.abs(theta - lam[:k]).max() > 1e-9 * max(lam[0], 1e-300):
             raise _lib.RomtimeHipError("device eigenvectors failed the Rayleigh-Ritz cross-check")
         return ops.gemm_nn(Z, ops.to_device(C, Z.device))
+
+
+def _world(group):
+    import torch.distributed as dist
+
+    return dist.get_world_size(group)
+
+
+def _share(total, group, rank=None):
+    """(first, count) of this rank's slice of ``total`` items: equal counts, the last slices overlap instead of
+    being shorter (the overlapping items are computed twice, identically), so all-gather pieces have one shape."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group) if rank is None else rank
+    cnt = -(-total // world)
+    return min(rank * cnt, total - cnt), cnt
+
+
+def _allgather(t, group):
+    import torch.distributed as dist
+
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(out, t.contiguous(), group=group)
+    return out
 
 
 def _allreduce(G, group):
@@ -201,7 +247,7 @@ def pod_device(X: torch.Tensor, num=None, tol=None, normalize=True, passes=None,
     if prof:
         ev[1].record()  # the current stream waits for the collective, so this event closes Gram + all-reduce
     colnorm, flag = ops.gram_scale(G, normalize)
-    eig = _SmallEig(G, extra=(flag, Gbuf[n * n:]))
+    eig = _SmallEig(G, extra=(flag, Gbuf[n * n:]), group=group)
     t1 = time.perf_counter()
     if normalize and int(eig.extra[0]) != 0:
         # the reference divides by a zero norm and scipy.linalg.svd then rejects the NaNs (pod.py:32-38)
@@ -301,7 +347,7 @@ def _pod_deflated(X, eig0, colnorm, normalize, num, tol, group, want_vt):
             C = _allreduce(ops.gemm_tn(Ql, Xc), group)  # Q^T X sums over the row slabs of all ranks
             Xc = Xc - ops.gemm_nn(Ql, C)
         G = _allreduce(ops.gram(Xc), group)
-        eig = _SmallEig(G)
+        eig = _SmallEig(G, group=group)
     Q = torch.cat(Q_acc, dim=1)[:, :r].contiguous() if (r > 0 and Q_acc) else X.new_zeros((X.shape[0], 0))
     VT = np.ascontiguousarray(np.hstack(W_acc)[:, :r].T) if (want_vt and W_acc) else (np.zeros((0, n)) if want_vt else None)
     return Q, s_full, energy, r, VT, levels
