@@ -66,6 +66,23 @@ def test_gemm_nn(ops, N, n, k, order):
     assert _rel(Y, X @ T) < 5e-14
 
 
+@pytest.mark.parametrize("N,n,k", [(20001, 70, 5), (16390, 64, 64), (40000, 97, 33), (65537, 129, 1)])
+def test_gemm_nn_tall_skinny_kernel(ops, N, n, k):
+    """Row-major X with N >= 64 x #CUs and k <= 64 takes the streaming kernel (tallskinny.hip): ragged row tail,
+    contraction length that is no multiple of the 32-column stage, odd output widths, odd leading dimension."""
+    from romtime_amd._lib import Context
+
+    rng = np.random.RandomState(N + n + k)
+    Xp = rng.standard_normal((N, n + 3))          # leading dimension n + 3 (odd for even n: scalar-load path)
+    X = ops.to_device(Xp)[:, :n]
+    T = rng.standard_normal((n, k))
+    Y = ops.gemm_nn(X, ops.to_device(T)).cpu().numpy()
+    assert Context.current().launch_info()["tile"][0] == 64   # the 64-row streaming tile, not the generic GEMM
+    assert _rel(Y, Xp[:, :n] @ T) < 5e-14
+    Xc = ops.to_device(np.ascontiguousarray(Xp[:, :n]))       # packed rows (16-byte vector loads when n is even)
+    assert _rel(ops.gemm_nn(Xc, ops.to_device(T)).cpu().numpy(), Xp[:, :n] @ T) < 5e-14
+
+
 def test_gram_scale(ops):
     rng = np.random.RandomState(5)
     X = rng.standard_normal((400, 24)) * 10.0 ** rng.uniform(-3, 3, 24)
