@@ -254,3 +254,44 @@ def test_device_sweep_matches_oracle_loop(bdf2):
         rel = np.linalg.norm(uN[i].T - ref_rom) / np.linalg.norm(ref_rom)
         assert rel <= 1e-10, (i, rel)
         assert np.abs(ref_rom).max() > 1e-4  # a non-trivial trajectory
+
+
+def test_hyper_reduced_sweep_synthetic_and_singular_system(ops):
+    """rt_hrom_bdf_sweep on random interpolation terms against oracle.hrom_solve, BDF1 and BDF2, r not a multiple of
+    16; one parameter point gets an identically zero K_N: its inverse tracking fails, the device-side LU fallback
+    reports the singular system, and the other parameter points are unaffected."""
+    from romtime_amd.sweep import hrom_bdf_sweep
+
+    rng = np.random.RandomState(3)
+    r, nt, n_mu, dt = 11, 9, 3, 1e-2
+    spd = lambda: (lambda a: a @ a.T + r * np.eye(r))(rng.standard_normal((r, r)))
+
+    def matrix_term(m, base, wobble):
+        # operator(mu, t) = (1 + wobble(mu, t)) * base + small random modes, as an m-mode interpolation expansion
+        cols = np.concatenate([base.reshape(-1, 1), 0.05 * rng.standard_normal((r * r, m - 1))], axis=1)
+        PT_U, _ = np.linalg.qr(rng.standard_normal((m, m)))
+        theta = np.concatenate([1.0 + wobble[..., None], 0.1 * rng.standard_normal((nt, n_mu, m - 1))], axis=-1)
+        return dict(PT_U=PT_U, basis_rom=cols, F=theta @ PT_U.T)
+
+    wob = lambda: 0.1 * rng.standard_normal((nt, n_mu))
+    for bdf2 in (True, False):
+        mass = matrix_term(4, spd(), 0.0 * wob())
+        lin = [matrix_term(3, spd(), wob()), matrix_term(5, rng.standard_normal((r, r)), wob())]
+        m_nl = 6
+        PTn, _ = np.linalg.qr(rng.standard_normal((m_nl, m_nl)))
+        nl = dict(PT_U=PTn, basis_rom=0.3 * rng.standard_normal((r * r, m_nl)), W=0.2 * rng.standard_normal((m_nl, r)),
+                  C=0.1 * rng.standard_normal((nt, n_mu, m_nl)), S=1.0 + 0.1 * rng.standard_normal((nt, n_mu)))
+        PTf, _ = np.linalg.qr(rng.standard_normal((4, 4)))
+        rhs = [dict(PT_U=PTf, basis_rom=rng.standard_normal((r, 4)), F=rng.standard_normal((nt, n_mu, 4)))]
+        uN = hrom_bdf_sweep(mass, lin, nl, rhs, dt, bdf2=bdf2).cpu().numpy()
+        for b in range(n_mu):
+            ref = oracle.hrom_solve(mass, lin, nl, rhs, b, r, nt, dt, bdf2)
+            assert np.linalg.norm(uN[b].T - ref) <= 1e-10 * np.linalg.norm(ref), (bdf2, b)
+        # parameter point 1: every operator coefficient zero -> K_N = 0
+        dead = lambda term: dict(term, F=np.where(np.arange(n_mu)[None, :, None] == 1, 0.0, term["F"]))
+        nl_dead = dict(nl, C=np.where(np.arange(n_mu)[None, :, None] == 1, 0.0, nl["C"]),
+                       S=np.where(np.arange(n_mu)[None, :] == 1, 0.0, nl["S"]))
+        uD = hrom_bdf_sweep(dead(mass), [dead(t) for t in lin], nl_dead, rhs, dt, bdf2=bdf2).cpu().numpy()
+        assert not np.all(np.isfinite(uD[1]))                      # singular: no finite answer is claimed
+        for b in (0, 2):
+            np.testing.assert_allclose(uD[b], uN[b], rtol=0, atol=1e-12 * np.abs(uN[b]).max())
