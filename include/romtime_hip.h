@@ -169,8 +169,9 @@ typedef struct {
  * No quantity of size N_h is touched.  uN_out: n_mu x nt x r (device). */
 int rt_hrom_bdf_sweep(rt_ctx* ctx, const rt_hsweep_desc* desc, double* uN_out);
 
-/* ---- small symmetric eigenproblem of the Gram matrix, on the device (3 <= n <= 512) ----------- */
-/* Householder tridiagonalisation (16 workgroups, matrix resident in LDS) + Sturm multisection:
+/* ---- small symmetric eigenproblem of the Gram matrix, on the device (3 <= n <= 1024) ---------- */
+/* Householder tridiagonalisation (32 cooperating workgroups, 128 for n > 512; matrix resident in LDS) + Sturm
+ * multisection:
  * lam (n, device) = all eigenvalues of the symmetric G (n x n row-major, not modified), DESCENDING.
  * status (device int, may be NULL): 0, or 1 if the inter-workgroup hand-off timed out (results
  * invalid).  Replaces the eigenvalue half of LAPACK's work inside scipy.linalg.svd (pod.py:38). */

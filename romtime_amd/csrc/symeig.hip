@@ -22,11 +22,12 @@
 
 namespace {
 
-constexpr int TW = 32;      // workgroups of the tridiagonalisation
+constexpr int TW_SMALL = 32;   // workgroups of the tridiagonalisation, n <= 512 (rows dealt cyclically)
+constexpr int TW_LARGE = 128;  // 512 < n <= 1024: 8 rows of 1024 per workgroup
 constexpr int LPR = 64;     // lanes per matrix row in the mat-vec / rank-2 update (TT / LPR rows per pass)
 constexpr int TT = 1024;    // threads per workgroup
 static_assert(LPR == 64, "row reductions use the whole-wave DPP sum");
-constexpr int NMAX = 512;
+constexpr int NMAX = 1024;     // largest supported n; the kernels are instantiated for 512 and 1024
 // inverse iterations per eigenvector: the shifts are eigenvalues to full precision, so the first solve already
 // amplifies the wanted direction by ~1/eps and the second removes what is left of the start vector (dstein also
 // stops after two or three); the caller's Rayleigh-Ritz step cross-checks the result
@@ -41,6 +42,7 @@ struct TriParams {
   double* e;         // n
   int* flags;        // [1] = arrival counter of the hand-offs, [3] = error
   int n;
+  int tw;            // cooperating workgroups
 };
 
 __device__ __forceinline__ void st_wt(double* p, double v) {
@@ -87,9 +89,10 @@ __device__ __forceinline__ double block_sum(double x, double* s_red) {
 // arithmetic being identical, bit-identically).  All O(n) vector work of a step (reflector, p.v, w, the
 // look-ahead row) is done by wave 0 alone in registers with shuffle reductions - 8 elements per lane -
 // so a step costs four workgroup barriers; the other 15 waves only do the O(n^2/P) mat-vec and update.
+template <int NM>
 __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int n = p.n, tid = threadIdx.x, wg = blockIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int n = p.n, TW = p.tw, tid = threadIdx.x, wg = blockIdx.x, lane = tid & 63, wid = tid >> 6;
   const int RB = (n + TW - 1) / TW;
   double* A = sm;                 // RB x n, local row li <-> global row li*TW + wg
   double* svb = sm + (size_t)RB * n;  // v, double buffered by step parity (2 x n)
@@ -97,7 +100,7 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
   double* sl = sw + n;            // current row k (entries j >= k), maintained by wave 0
   __shared__ int s_abort;
   __shared__ double s_tau;
-  constexpr int PER = NMAX / 64;
+  constexpr int PER = NM / 64;
 
   for (int q = tid; q < RB * n; q += TT) {
     const int li = q / n, j = q % n, gi = li * TW + wg;
@@ -275,11 +278,12 @@ __global__ void symeig_init_kernel(int* flags, double* tau, int n) {
 // so an eigenvalue is shared by TWO waves with 2 shifts per lane, and a workgroup is four waves = two
 // eigenvalues: its waves occupy the four SIMDs of one CU, n/2 workgroups put one wave on every SIMD of the chip.
 constexpr int BIS_NS = 2;  // shifts per lane
+template <int NM>
 __global__ __launch_bounds__(256) void symeig_bisect_kernel(const double* __restrict__ d, const double* __restrict__ e,
                                                             int n, int first, int count, double* __restrict__ lam,
                                                             const int* flags, int* status) {
   if (status && blockIdx.x == 0 && threadIdx.x == 0) *status = flags[3];
-  __shared__ double sd[NMAX], se2[NMAX];
+  __shared__ double sd[NM], se2[NM];
   __shared__ int s_first[2][4];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, half = wid & 1;
   double glo = 1e300, ghi = -1e300, emax = 0.0;
@@ -352,8 +356,9 @@ constexpr int RBK = 4;  // reflectors applied together in the back-transformatio
 // Block b holds the reflectors k0 - u, u = 0..3, k0 = n - 3 - 4 b, applied in that order.  Their mutual inner
 // products do not depend on the vector being transformed, so they are computed once here (one wave per block)
 // and shared by all eigenvectors: C[6 b + {0..5}] = v1.v0, v2.v0, v2.v1, v3.v0, v3.v1, v3.v2.
+template <int NM>
 __global__ __launch_bounds__(64) void symeig_wy_kernel(const double* __restrict__ V, int n, double* __restrict__ C) {
-  constexpr int PER = NMAX / 64;
+  constexpr int PER = NM / 64;
   const int b = blockIdx.x, lane = threadIdx.x, k0 = n - 3 - RBK * b;
   double v[RBK][PER];
 #pragma unroll
@@ -378,12 +383,15 @@ __global__ __launch_bounds__(64) void symeig_wy_kernel(const double* __restrict_
 }
 
 // one wave per eigenvector: inverse iteration on T - lambda I, then back-transformation
+template <int NM>
 __global__ __launch_bounds__(64) void symeig_vectors_kernel(const VecParams p) {
   // read-only inputs of the serial sweeps (dd, ee, and y / z alternately) and write-only outputs (ra, ub, ud, lm,
   // piv) live in DIFFERENT arrays, so the loads of later steps can be issued ahead of the dependent arithmetic:
   // the chain per step is then a reciprocal and three FMAs instead of an LDS round trip per access
-  __shared__ double dd[NMAX], ee[NMAX + 1], ra[NMAX], ub[NMAX], ud[NMAX], lm[NMAX], z[NMAX], y[NMAX];
-  __shared__ unsigned char piv[NMAX];
+  extern __shared__ __attribute__((aligned(16))) double vsm[];  // 8 arrays of NM (+1) doubles and NM pivot flags
+  double *dd = vsm, *ee = dd + NM, *ra = ee + NM + 8, *ub = ra + NM, *ud = ub + NM, *lm = ud + NM, *z = lm + NM,
+         *y = z + NM;
+  unsigned char* piv = reinterpret_cast<unsigned char*>(y + NM);
   const int n = p.n, t = blockIdx.x, lane = threadIdx.x;
   const double lambda = p.lam[t];
   double tnorm = 0.0;
@@ -466,7 +474,7 @@ __global__ __launch_bounds__(64) void symeig_vectors_kernel(const VecParams p) {
   // x = Q z = H_0 H_1 ... H_{n-3} z : apply the reflectors from the last to the first.  A reflector row comes
   // from L2 / HBM (~1-2 us away) while applying one takes ~0.1 us, so the rows are fetched RB at a time, one
   // whole block ahead of the block being applied (lane owns j = lane + 64 q).
-  constexpr int PER = NMAX / 64;
+  constexpr int PER = NM / 64;
   double zr[PER], vc[RBK][PER], vn[RBK][PER];
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
@@ -536,7 +544,13 @@ extern "C" int rt_sym_eig_values_part(rt_ctx* ctx, const double* G, int64_t n, i
   if (!ctx) return RT_ERR_ARG;
   RT_ARG_CHECK(ctx, G && lam && n >= 3 && first >= 0 && count >= 1 && first + count <= n);
   if (n > NMAX) {
-    ctx->err = "rt_sym_eig_values: n > 512 not supported (the matrix must fit the LDS of 16 CUs)";
+    ctx->err = "rt_sym_eig_values: n > 1024 not supported (the matrix must stay resident in the LDS of <= 128 CUs)";
+    return RT_ERR_UNSUPPORTED;
+  }
+  const bool large = n > 512;
+  const int tw = large ? TW_LARGE : TW_SMALL;
+  if (tw > ctx->num_cus) {  // the cooperating workgroups must all be resident
+    ctx->err = "rt_sym_eig_values: not enough compute units for the cooperative tridiagonalisation";
     return RT_ERR_UNSUPPORTED;
   }
   // composite arena: V (n*n) | P (2n) | tau | d | e | flags
@@ -549,25 +563,35 @@ extern "C" int rt_sym_eig_values_part(rt_ctx* ctx, const double* G, int64_t n, i
   if (rc != RT_OK) return rc;
   char* b8 = static_cast<char*>(base);
   TriParams tp;
-  tp.G = G; tp.n = (int)n;
+  tp.G = G; tp.n = (int)n; tp.tw = tw;
   tp.V = reinterpret_cast<double*>(b8 + oV); tp.P = reinterpret_cast<double*>(b8 + oP);
   tp.tau = reinterpret_cast<double*>(b8 + oT); tp.d = reinterpret_cast<double*>(b8 + oD);
   tp.e = reinterpret_cast<double*>(b8 + oE); tp.flags = reinterpret_cast<int*>(b8 + oF);
   hipStream_t st = ctx->stream;
   hipLaunchKernelGGL(symeig_init_kernel, dim3(1), dim3(256), 0, st, tp.flags, tp.tau, (int)n);
 
-  const int RB = (int)((n + TW - 1) / TW);
+  const int RB = (int)((n + tw - 1) / tw);
   const size_t lds = sizeof(double) * ((size_t)RB * n + 4 * n + 16);  // A slab | v (x2) | w | row
   static bool attr_set = false;
   if (!attr_set) {
-    RT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&symeig_tridiag_kernel),
+    RT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&symeig_tridiag_kernel<512>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+    RT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&symeig_tridiag_kernel<1024>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
     attr_set = true;
   }
-  hipLaunchKernelGGL(symeig_tridiag_kernel, dim3(TW), dim3(TT), lds, st, tp);
-  RT_HIP_CHECK(ctx, hipGetLastError());
-  hipLaunchKernelGGL(symeig_bisect_kernel, dim3((unsigned)((count + 1) / 2)), dim3(256), 0, st, tp.d, tp.e, (int)n,
-                     (int)first, (int)count, lam, tp.flags, status);
+  const dim3 bgrid((unsigned)((count + 1) / 2));
+  if (large) {
+    hipLaunchKernelGGL(symeig_tridiag_kernel<1024>, dim3(tw), dim3(TT), lds, st, tp);
+    RT_HIP_CHECK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(symeig_bisect_kernel<1024>, bgrid, dim3(256), 0, st, tp.d, tp.e, (int)n, (int)first, (int)count,
+                       lam, tp.flags, status);
+  } else {
+    hipLaunchKernelGGL(symeig_tridiag_kernel<512>, dim3(tw), dim3(TT), lds, st, tp);
+    RT_HIP_CHECK(ctx, hipGetLastError());
+    hipLaunchKernelGGL(symeig_bisect_kernel<512>, bgrid, dim3(256), 0, st, tp.d, tp.e, (int)n, (int)first, (int)count,
+                       lam, tp.flags, status);
+  }
   RT_HIP_CHECK(ctx, hipGetLastError());
   ctx->eig.d = tp.d; ctx->eig.e = tp.e; ctx->eig.V = tp.V; ctx->eig.tau = tp.tau; ctx->eig.n = n; ctx->eig.base = base;
   return RT_OK;
@@ -588,9 +612,25 @@ extern "C" int rt_sym_eig_vectors(rt_ctx* ctx, int64_t n, int64_t k, const doubl
   int rc = rt_scratch(ctx, sizeof(double) * 6 * (size_t)nblk, &cbuf);  // leaf arena: free between the two calls
   if (rc != RT_OK) return rc;
   vp.C = static_cast<const double*>(cbuf);
-  hipLaunchKernelGGL(symeig_wy_kernel, dim3((unsigned)nblk), dim3(64), 0, ctx->stream, vp.V, (int)n,
-                     static_cast<double*>(cbuf));
-  hipLaunchKernelGGL(symeig_vectors_kernel, dim3((unsigned)k), dim3(64), 0, ctx->stream, vp);
+  static bool vattr_set = false;
+  if (!vattr_set) {
+    RT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&symeig_vectors_kernel<512>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    RT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&symeig_vectors_kernel<1024>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    vattr_set = true;
+  }
+  if (n > 512) {
+    const size_t vlds = sizeof(double) * (8 * 1024 + 8) + 1024;
+    hipLaunchKernelGGL(symeig_wy_kernel<1024>, dim3((unsigned)nblk), dim3(64), 0, ctx->stream, vp.V, (int)n,
+                       static_cast<double*>(cbuf));
+    hipLaunchKernelGGL(symeig_vectors_kernel<1024>, dim3((unsigned)k), dim3(64), vlds, ctx->stream, vp);
+  } else {
+    const size_t vlds = sizeof(double) * (8 * 512 + 8) + 512;
+    hipLaunchKernelGGL(symeig_wy_kernel<512>, dim3((unsigned)nblk), dim3(64), 0, ctx->stream, vp.V, (int)n,
+                       static_cast<double*>(cbuf));
+    hipLaunchKernelGGL(symeig_vectors_kernel<512>, dim3((unsigned)k), dim3(64), vlds, ctx->stream, vp);
+  }
   RT_HIP_CHECK(ctx, hipGetLastError());
   return RT_OK;
 }

@@ -8,7 +8,7 @@ Algorithm (device work through the C ABI, see include/romtime_hip.h):
   pass 1   G = X^T X                        rt_gram        (FP64 MFMA; the only O(N n^2) step)
            [row-sharded X: all-reduce G over RCCL/xGMI here]
            colnorm = sqrt(diag G), G <- D^-1 G D^-1        rt_gram_scale  (normalize=True, pod.py:31-33)
-           G = W L W^T                      rt_sym_eig_values / _vectors (device; host LAPACK for n > 512)
+           G = W L W^T                      rt_sym_eig_values / _vectors (device; host LAPACK for n > 1024)
            sigma = sqrt(L), energy, truncation -> r
            Q = X (D^-1 W_r S_r^-1)          rt_gemm_nn     (back-projection)
 
@@ -32,7 +32,7 @@ from . import _lib, ops
 
 DROP_TOLERANCE = 1e-7  # pod.py:4 (the reference's docstring says 1e-8; the code is 1e-7)
 DEVICE_EIG = True      # small eigenproblem on the device (rt_sym_eig_*); False = host LAPACK
-DEVICE_EIG_MAX_N = 512
+DEVICE_EIG_MAX_N = 1024
 RR_GAP = 1e-4           # smallest eigenvalue gap (relative to lam_1) for which inverse iteration is trusted as is
 TWO_PASS_RATIO = 1e-2  # one Gram pass: vectors good to ~eps (sigma_1/sigma_i)^2 <= 2e-12 above this ratio
 
@@ -116,7 +116,7 @@ def _inv_or_zero(s):
 
 class _SmallEig:
     """Eigen-decomposition of the n x n Gram matrix: all eigenvalues (host array, descending) at once,
-    leading eigenvectors on request (device, n x k).  3 <= n <= 512 runs on the device
+    leading eigenvectors on request (device, n x k).  3 <= n <= 1024 runs on the device
     (rt_sym_eig_values / rt_sym_eig_vectors, Rayleigh-Ritz polish on G when kept eigenvalues are
     closer than RR_GAP * lam_1); other sizes use host LAPACK."""
 

@@ -199,7 +199,7 @@ def test_unsupported_sizes_fail_loudly(ops):
         ops.gemm_tn(torch.ones((4, 2), dtype=torch.float64, device="cuda"), torch.ones((5, 2), dtype=torch.float64, device="cuda"))
 
 
-@pytest.mark.parametrize("n", [3, 17, 64, 200, 256, 512])
+@pytest.mark.parametrize("n", [3, 17, 64, 200, 256, 512, 513, 777, 1024])
 @pytest.mark.parametrize("kind", ["decay", "flat", "cluster"])
 def test_sym_eig_device(ops, n, kind):
     """Device tridiagonalisation + multisection + inverse iteration against LAPACK."""
