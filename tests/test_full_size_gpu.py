@@ -23,7 +23,8 @@ def _snapshots(N, n, decay, seed):
     return Z @ (s[:, None] * V0.T)
 
 
-@pytest.mark.parametrize("N,n,r,decay", [(100_000, 256, 40, 6.0), (1_000_000, 512, 40, 8.0)])
+@pytest.mark.parametrize("N,n,r,decay", [(100_000, 256, 40, 6.0), (1_000_000, 512, 40, 8.0), (200_000, 700, 50, 6.0),
+                                         (150_000, 1024, 64, 5.0)])
 def test_pod_full_size_properties(ops, N, n, r, decay):
     """Configs 2 and 3: Q^T Q = I, sum sigma^2 = ||X_n||_F^2, and ||X_n - Q Q^T X_n||_F^2 = sum_{i>r} sigma_i^2."""
     from romtime_amd import pod
