@@ -78,6 +78,11 @@ int rt_gemm_tn(rt_ctx* ctx, const double* A, int64_t lda, int a_layout, const do
  * The POD back-projection U_r = X (D^-1 W_r S_r^-1) and V.dot(uN) (rom.py:111-112). */
 int rt_gemm_nn(rt_ctx* ctx, const double* X, int64_t ldx, int x_layout, const double* T, int64_t ldt,
                int64_t N, int64_t n, int64_t k, double* Y, int64_t ldy, int y_layout);
+/* Y = beta Y + alpha X T, same operands.  The deflation of the multi-level POD, X <- X - Q (Q^T X), in place
+ * (Gram-Schmidt sweep between the levels; the reference gets deep spectra from dgesvd itself, pod.py:38). */
+int rt_gemm_nn_axpby(rt_ctx* ctx, const double* X, int64_t ldx, int x_layout, const double* T, int64_t ldt,
+                     int64_t N, int64_t n, int64_t k, double alpha, double beta, double* Y, int64_t ldy,
+                     int y_layout);
 
 /* Out-of-place transpose: dst (cols x rows, row-major, ld_dst) = src (rows x cols, row-major, ld_src)^T. */
 int rt_transpose(rt_ctx* ctx, const double* src, int64_t rows, int64_t cols, int64_t ld_src, double* dst,

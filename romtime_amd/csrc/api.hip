@@ -265,19 +265,24 @@ int rt_gemm_tn(rt_ctx* ctx, const double* A, int64_t lda, int a_layout, const do
 
 int rt_gemm_nn(rt_ctx* ctx, const double* X, int64_t ldx, int x_layout, const double* T, int64_t ldt, int64_t N,
                int64_t n, int64_t k, double* Y, int64_t ldy, int y_layout) {
+  return rt_gemm_nn_axpby(ctx, X, ldx, x_layout, T, ldt, N, n, k, 1.0, 0.0, Y, ldy, y_layout);
+}
+
+int rt_gemm_nn_axpby(rt_ctx* ctx, const double* X, int64_t ldx, int x_layout, const double* T, int64_t ldt, int64_t N,
+                     int64_t n, int64_t k, double alpha, double beta, double* Y, int64_t ldy, int y_layout) {
   if (!ctx) return RT_ERR_ARG;
   RT_ARG_CHECK(ctx, X && T && Y && N >= 1 && n >= 1 && k >= 1 && ldt >= k);
   RT_ARG_CHECK(ctx, (x_layout == RT_ROW_MAJOR || x_layout == RT_COL_MAJOR) &&
                         (y_layout == RT_ROW_MAJOR || y_layout == RT_COL_MAJOR));
   RT_ARG_CHECK(ctx, ldx >= (x_layout == RT_ROW_MAJOR ? n : N) && ldy >= (y_layout == RT_ROW_MAJOR ? k : N));
-  if (x_layout == RT_ROW_MAJOR && y_layout == RT_ROW_MAJOR) {  // tall X, few columns out: the streaming kernel
-    const int rc = rt_tallskinny(ctx, X, ldx, T, ldt, N, n, k, Y, ldy);
+  if (x_layout == RT_ROW_MAJOR && y_layout == RT_ROW_MAJOR && alpha == 1.0 && beta == 0.0) {
+    const int rc = rt_tallskinny(ctx, X, ldx, T, ldt, N, n, k, Y, ldy);  // tall X, few columns out: streaming kernel
     if (rc != RT_ERR_UNSUPPORTED) return rc;
   }
   // contraction over the n columns of X: A(c, i) = X[i][c]
   const int64_t a_ks = (x_layout == RT_ROW_MAJOR) ? 1 : ldx, a_ms = (x_layout == RT_ROW_MAJOR) ? ldx : 1;
   const int64_t c_rs = (y_layout == RT_ROW_MAJOR) ? ldy : 1, c_cs = (y_layout == RT_ROW_MAJOR) ? 1 : ldy;
-  return rt_gemm_strided(ctx, X, a_ks, a_ms, T, ldt, 1, n, N, k, Y, c_rs, c_cs, false, false);
+  return rt_gemm_strided(ctx, X, a_ks, a_ms, T, ldt, 1, n, N, k, Y, c_rs, c_cs, false, false, alpha, beta);
 }
 
 int rt_transpose(rt_ctx* ctx, const double* src, int64_t rows, int64_t cols, int64_t ld_src, double* dst,

@@ -54,9 +54,10 @@ int rt_scratch2(rt_ctx* ctx, size_t bytes, void** out);
 //   C(i,j) at C[i*c_rs + j*c_cs]
 // `symmetric`: A == B, M == Nn; only tiles on/above the diagonal are computed, then mirrored.
 // `allow_split`: contraction may be split over workgroups (deterministic slab reduction).
+// `alpha`, `beta`: C = alpha * (product) + beta * C (beta == 0: C is not read).
 int rt_gemm_strided(rt_ctx* ctx, const double* A, int64_t a_ks, int64_t a_ms, const double* B, int64_t b_ks,
                     int64_t b_ns, int64_t K, int64_t M, int64_t Nn, double* C, int64_t c_rs, int64_t c_cs,
-                    bool symmetric, bool allow_split);
+                    bool symmetric, bool allow_split, double alpha = 1.0, double beta = 0.0);
 
 // Specialised Gram kernel (gram_mfma.hip); RT_ERR_UNSUPPORTED means "use rt_gemm_strided".
 int rt_gram128(rt_ctx* ctx, const double* X, int64_t ks, int64_t ms, int64_t K, int64_t n, double* G);

@@ -133,14 +133,18 @@ __global__ __launch_bounds__(NTHREADS, 2) void gemm_f64_mfma_kernel(const GemmPa
       for (int r = 0; r < 4; ++r) {
         const long row = m0 + wm * 16 * MT + i * 16 + l4 + 4 * r;
         const long col = n0 + wn * 16 * NT + j * 16 + l15;
-        if (row < p.M && col < p.Nn) Cs[row * p.c_rs + col * p.c_cs] = acc[i][j][r];
+        if (row < p.M && col < p.Nn) {
+          double* dst = Cs + row * p.c_rs + col * p.c_cs;
+          const double v = p.c_alpha * acc[i][j][r];  // alpha == 1 for slabs and plain products: exact
+          *dst = (p.c_beta != 0.0) ? fma(p.c_beta, *dst, v) : v;
+        }
       }
 }
 
 // Fixed-order sum of the split slabs (row-major M x Nn, ld = Nn).  symmetric: element (i,j)
 // with i > j is read from (j,i), which also makes the result exactly symmetric.
 __global__ void gemm_reduce_kernel(const double* __restrict__ slab, long split_stride, int splits, double* C,
-                                   long c_rs, long c_cs, long M, long Nn, int symmetric) {
+                                   long c_rs, long c_cs, long M, long Nn, int symmetric, double alpha, double beta) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= M * Nn) return;
   const long i = idx / Nn, j = idx % Nn;
@@ -152,7 +156,9 @@ __global__ void gemm_reduce_kernel(const double* __restrict__ slab, long split_s
   const double* src = slab + si * Nn + sj;
   double sum = 0.0;
   for (int s = 0; s < splits; ++s) sum += src[(long)s * split_stride];
-  C[i * c_rs + j * c_cs] = sum;
+  double* dst = C + i * c_rs + j * c_cs;
+  const double v = alpha * sum;
+  *dst = (beta != 0.0) ? fma(beta, *dst, v) : v;
 }
 
 template <int MT, int NT, bool KCA, bool KCB, bool SKINNY = false>
@@ -205,7 +211,7 @@ int tile_units(long extent) {  // tile extent in units of 32 (1..4)
 
 int rt_gemm_strided(rt_ctx* ctx, const double* A, int64_t a_ks, int64_t a_ms, const double* B, int64_t b_ks,
                     int64_t b_ns, int64_t K, int64_t M, int64_t Nn, double* C, int64_t c_rs, int64_t c_cs,
-                    bool symmetric, bool allow_split) {
+                    bool symmetric, bool allow_split, double alpha, double beta) {
   RT_ARG_CHECK(ctx, A && B && C);
   RT_ARG_CHECK(ctx, K >= 0 && M >= 1 && Nn >= 1);
   RT_ARG_CHECK(ctx, a_ks == 1 || a_ms == 1 || M == 1 || K == 1);
@@ -263,8 +269,10 @@ int rt_gemm_strided(rt_ctx* ctx, const double* A, int64_t a_ks, int64_t a_ms, co
     if (rc != RT_OK) return rc;
     p.C = static_cast<double*>(slab);
     p.c_rs = Nn; p.c_cs = 1; p.c_split_stride = M * Nn;
+    p.c_alpha = 1.0; p.c_beta = 0.0;  // slabs hold plain partial products; alpha / beta are applied by the reduction
   } else {
     p.C = C; p.c_rs = c_rs; p.c_cs = c_cs; p.c_split_stride = 0;
+    p.c_alpha = alpha; p.c_beta = beta;
   }
   const int grid = (splits == 1) ? p.ntiles : 8 * ((splits + 7) / 8) * p.ntiles;
   ctx->last_grid = grid; ctx->last_splits = splits; ctx->last_tile = BM * 1000 + BN;
@@ -300,7 +308,7 @@ int rt_gemm_strided(rt_ctx* ctx, const double* A, int64_t a_ks, int64_t a_ms, co
     const long total = M * Nn;
     hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream,
                        p.C, p.c_split_stride, splits, C, (long)c_rs, (long)c_cs, (long)M, (long)Nn,
-                       symmetric ? 1 : 0);
+                       symmetric ? 1 : 0, alpha, beta);
     RT_HIP_CHECK(ctx, hipGetLastError());
   }
   return RT_OK;

@@ -17,6 +17,7 @@ struct GemmParams {
   double* C; long c_rs, c_cs, c_split_stride;
   long K, M, Nn, k_per_split;
   int tiles_m, tiles_n, ntiles, splits, symmetric, vecA, vecB;
+  double c_alpha, c_beta;  // direct (unsplit) store: C = c_alpha * acc (+ c_beta * C when c_beta != 0)
 };
 
 // One operand panel: KB (contraction) x BT (tile extent).

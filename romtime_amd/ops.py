@@ -93,10 +93,12 @@ def gemm_tn(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     return Cm
 
 
-def gemm_nn(X: torch.Tensor, T: torch.Tensor) -> torch.Tensor:
-    """Y = X T (N x k, row-major). rt_gemm_nn."""
+def gemm_nn(X: torch.Tensor, T: torch.Tensor, out: torch.Tensor = None, alpha: float = 1.0, beta: float = 0.0) -> torch.Tensor:
+    """Y = X T (N x k, row-major), or ``out = beta out + alpha X T`` in place (``out``: N x k with unit column
+    stride).  rt_gemm_nn / rt_gemm_nn_axpby."""
     ctx = Context.current()
     if T.dim() == 1:
+        assert out is None
         return gemm_nn(X, T.unsqueeze(1)).squeeze(1)
     X, ldx, lx = _layout(X)
     T = T.contiguous()
@@ -104,8 +106,16 @@ def gemm_nn(X: torch.Tensor, T: torch.Tensor) -> torch.Tensor:
     n2, k = T.shape
     if n != n2:
         raise RomtimeHipError(f"gemm_nn: inner dimensions differ ({n} vs {n2})")
-    Y = torch.empty((N, k), dtype=torch.float64, device=X.device)
-    ctx.check(ctx.lib.rt_gemm_nn(ctx.handle, _ptr(X), ldx, lx, _ptr(T), k, N, n, k, _ptr(Y), k, ROW_MAJOR), "rt_gemm_nn")
+    if out is None:
+        if beta != 0.0:
+            raise RomtimeHipError("gemm_nn: beta != 0 needs an output to accumulate into")
+        Y, ldy, ly = torch.empty((N, k), dtype=torch.float64, device=X.device), k, ROW_MAJOR
+    else:
+        Y, ldy, ly = _layout(out)
+        if Y is not out or tuple(out.shape) != (N, k):
+            raise RomtimeHipError("gemm_nn: `out` must be an N x k float64 CUDA tensor with a unit stride")
+    ctx.check(ctx.lib.rt_gemm_nn_axpby(ctx.handle, _ptr(X), ldx, lx, _ptr(T), k, N, n, k, float(alpha), float(beta),
+                                       _ptr(Y), ldy, ly), "rt_gemm_nn_axpby")
     return Y
 
 

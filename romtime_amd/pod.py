@@ -341,11 +341,14 @@ def _pod_deflated(X, eig0, colnorm, normalize, num, tol, group, want_vt):
         if r <= got or k == 0 or got >= n or levels >= MAX_LEVELS or tail.size == 0 or tail[0] <= 0.0:
             break
         # deflate: X <- X - Q (Q^T X), twice (classical Gram-Schmidt needs the second sweep)
-        if Xc is None:
-            Xc = X / colnorm[None, :] if normalize else X.clone()
-        for _ in range(2):
+        fresh = Xc is None     # first level: the caller's X must stay intact, later levels update Xc in place
+        if fresh:
+            Xc = X / colnorm[None, :] if normalize else X
+        for sweep in range(2):
             C = _allreduce(ops.gemm_tn(Ql, Xc), group)  # Q^T X sums over the row slabs of all ranks
-            Xc = Xc - ops.gemm_nn(Ql, C)
+            if fresh and not normalize and sweep == 0:
+                Xc = Xc.clone()                         # the caller's X must stay intact
+            ops.gemm_nn(Ql, C, out=Xc, alpha=-1.0, beta=1.0)   # Xc -= Ql C in the GEMM's own epilogue
         G = _allreduce(ops.gram(Xc), group)
         eig = _SmallEig(G, group=group)
     Q = torch.cat(Q_acc, dim=1)[:, :r].contiguous() if (r > 0 and Q_acc) else X.new_zeros((X.shape[0], 0))

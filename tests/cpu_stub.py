@@ -47,8 +47,11 @@ def gemm_tn(A, B):
     return A.T @ B
 
 
-def gemm_nn(X, T):
-    return X @ T
+def gemm_nn(X, T, out=None, alpha=1.0, beta=0.0):
+    if out is None:
+        return alpha * (X @ T) if alpha != 1.0 else X @ T
+    out.copy_(beta * out + alpha * (X @ T))
+    return out
 
 
 def deim_greedy(Phi, want_margin=True):

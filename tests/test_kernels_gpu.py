@@ -295,3 +295,20 @@ def test_hyper_reduced_sweep_synthetic_and_singular_system(ops):
         assert not np.all(np.isfinite(uD[1]))                      # singular: no finite answer is claimed
         for b in (0, 2):
             np.testing.assert_allclose(uD[b], uN[b], rtol=0, atol=1e-12 * np.abs(uN[b]).max())
+
+
+@pytest.mark.parametrize("N,n,k", [(5000, 24, 200), (40000, 8, 512), (3001, 33, 70)])
+def test_gemm_nn_accumulate(ops, N, n, k):
+    """out = beta out + alpha X T in the GEMM's epilogue (rt_gemm_nn_axpby): the deflation update X -= Q (Q^T X)."""
+    rng = np.random.RandomState(N + k)
+    X, T, Y0 = rng.standard_normal((N, n)), rng.standard_normal((n, k)), rng.standard_normal((N, k))
+    Y = ops.to_device(Y0)
+    ret = ops.gemm_nn(ops.to_device(X), ops.to_device(T), out=Y, alpha=-1.0, beta=1.0)
+    assert ret is Y
+    assert _rel(Y.cpu().numpy(), Y0 - X @ T) < 5e-14
+    Y = ops.to_device(Y0)
+    ops.gemm_nn(ops.to_device(X), ops.to_device(T), out=Y, alpha=0.5, beta=-2.0)
+    assert _rel(Y.cpu().numpy(), -2.0 * Y0 + 0.5 * (X @ T)) < 5e-14
+    Y = ops.to_device(np.full((N, k), np.nan))          # beta == 0: the output is not read
+    ops.gemm_nn(ops.to_device(X), ops.to_device(T), out=Y)
+    assert _rel(Y.cpu().numpy(), X @ T) < 5e-14
