@@ -144,3 +144,27 @@ def test_parameter_sampler_draws(golden_sampler):
     draws = list(ParameterSampler(grid, n_iter=8, random_state=np.random.RandomState(0)))
     arr = np.array([[d[k] for k in g["keys"]] for d in draws])
     np.testing.assert_allclose(arr, g["draws"], rtol=1e-15)
+
+
+def test_closed_form_p1_operators_match_the_reference_known_answer_tables():
+    """The literal operator tables of the reference's own FEniCS test (tests/test_mpf1.py:170-260: stiffness and mass
+    of the fixed-mesh heat problem, nx = 3, L = 2, three ParameterSampler draws with RandomState(0), t = 0) pin the
+    closed-form P1 assembly that the benchmarks and the FEniCS-free tests use (romtime_amd.testing.mock)."""
+    from sklearn.model_selection import ParameterSampler
+    from scipy.stats import uniform
+
+    from romtime_amd.testing.mock import MockSolver
+
+    grid = {"delta": uniform(0.01, 1.99), "beta": uniform(1.0, 9.0), "alpha_0": uniform(0.01, 1.99)}  # test_mpf1.py:95-103
+    samples = list(ParameterSampler(param_distributions=grid, n_iter=3, random_state=np.random.RandomState(0)))
+    solver = MockSolver(domain={"L0": 2.0, "nx": 3, "T": 10.0, "nt": 500})
+    solver.setup()
+    stiff_diag = [3.30641662, 3.2829526, 2.64239565]          # test_mpf1.py:176,194,212 (interior diagonal entries)
+    for sample, d in zip(samples, stiff_diag):
+        Ah = solver.assemble_stiffness(mu=sample, t=0.0).toarray().flatten()
+        Mh = solver.assemble_mass(mu=sample, t=0.0).toarray().flatten()
+        expected_A = np.array([1.0, 0, 0, 0, -d / 2, d, -d / 2, 0, 0, -d / 2, d, -d / 2, 0, 0, 0, 1.0])
+        expected_M = np.array([1.0, 0, 0, 0, 0.11111111, 0.44444444, 0.11111111, 0, 0, 0.11111111, 0.44444444,
+                               0.11111111, 0, 0, 0, 1.0])                                 # test_mpf1.py:229-245
+        np.testing.assert_array_almost_equal(Ah, expected_A, decimal=6)                   # the reference's own bar
+        np.testing.assert_array_almost_equal(Mh, expected_M, decimal=6)
