@@ -168,3 +168,20 @@ def test_closed_form_p1_operators_match_the_reference_known_answer_tables():
                                0.11111111, 0, 0, 0, 1.0])                                 # test_mpf1.py:229-245
         np.testing.assert_array_almost_equal(Ah, expected_A, decimal=6)                   # the reference's own bar
         np.testing.assert_array_almost_equal(Mh, expected_M, decimal=6)
+
+
+def test_closed_form_moving_mesh_stiffness_matches_the_reference_table():
+    """tests/test_moving_mesh.py:102-150: stiffness of the moving-mesh solver (nx = 5, L(t) = 1 + sin(omega t),
+    alpha_0 = 0.5) at t = 0 and t = 5; the reference's CSR keeps two explicit zeros in the Dirichlet rows, which
+    eliminate_zeros (utils.py:152-168) removes before anything is used as a snapshot."""
+    from romtime_amd.testing.mock import MockSolver
+
+    solver = MockSolver(domain={"L0": 1.0, "nx": 5, "T": 5.0, "nt": 100}, Lt=lambda t, **mu: 1.0 + np.sin(mu["omega"] * t))
+    solver.setup()
+    mu = {"alpha_0": 0.5, "epsilon": 0.0, "omega": np.pi / 2.0 / 10}
+    expected0 = np.array([1.0, 0.0, -2.5, 5.0, -2.5, -2.5, 5.0, -2.5, -2.5, 5.0, -2.5, -2.5, 5.0, -2.5, 0.0, 1.0])
+    expected1 = np.array([1.0, 0.0, -38.07611845, 76.15223689, -38.07611845, -38.07611845, 76.15223689, -38.07611845,
+                          -38.07611845, 76.15223689, -38.07611845, -38.07611845, 76.15223689, -38.07611845, 0.0, 1.0])
+    for t, expected in ((0.0, expected0), (5.0, expected1), (0.0, expected0)):
+        data = oracle.eliminate_zeros(solver.assemble_stiffness(mu=mu, t=t)).data
+        np.testing.assert_allclose(data, expected[expected != 0.0], rtol=1e-9)
