@@ -179,20 +179,29 @@ struct GramReduceParams {
   unsigned char first[MAX_TILES], count[MAX_TILES];  // per upper-triangular tile, in its own launch's slots
 };
 
+// Each thread on or above the diagonal sums its element over the 8 XCD slabs x sub-splits in a fixed order (rows
+// of a slab are contiguous, so the reads coalesce) and writes it to both (i, j) and (j, i): G is exactly symmetric
+// and the slabs are read once (the mirrored half used to re-read them column-wise).
 __global__ void gram_reduce_kernel(const GramReduceParams p) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= p.n * p.n) return;
   const long i = idx / p.n, j = idx % p.n;
-  const long a = (i < j) ? i : j, b = (i < j) ? j : i;  // read the upper element: exact symmetry
-  const int tm = (int)(a / BT), tn = (int)(b / BT);
+  if (i > j) return;
+  const int tm = (int)(i / BT), tn = (int)(j / BT);
   const int t = tm * p.tiles1 - tm * (tm - 1) / 2 + (tn - tm);
-  const long off = (a % BT) * BT + (b % BT);
+  const long off = (i % BT) * BT + (j % BT);
   const double* slab = (tm == tn) ? p.slab_diag : p.slab_off;
   const int nslots = (tm == tn) ? p.nslots_diag : p.nslots_off;
+  const int cnt = p.count[t];
+  const double* base = slab + (long)p.first[t] * (BT * BT) + off;
   double sum = 0.0;
-  for (int x = 0; x < 8; ++x)
-    for (int q = 0; q < p.count[t]; ++q) sum += slab[((long)x * nslots + p.first[t] + q) * (BT * BT) + off];
+  for (int x = 0; x < 8; ++x) {
+    const double* src = base + (long)x * nslots * (BT * BT);
+#pragma unroll 4
+    for (int q = 0; q < cnt; ++q) sum += src[(long)q * (BT * BT)];
+  }
   p.G[idx] = sum;
+  if (i != j) p.G[j * p.n + i] = sum;
 }
 
 template <bool KC, bool DIAG>
