@@ -1,22 +1,23 @@
-// Symmetric eigensolver for the small n x n Gram matrix of the POD (n <= 512), on the device:
+// Symmetric eigensolver for the small n x n Gram matrix of the POD (3 <= n <= 1024), on the device:
 // all eigenvalues + the k leading eigenvectors, so that `orth` never leaves the GPU for the step
-// that LAPACK dsyevd (15 ms at n = 512 on the host, 13 ms in rocSOLVER) would otherwise dominate.
+// that LAPACK dsyevd (19 ms at n = 512 on the host, 13 ms in rocSOLVER) would otherwise dominate.
 //
 //   1. symeig_tridiag_kernel   Householder tridiagonalisation Q^T G Q = T (LAPACK dsytd2 recurrences).
-//      16 workgroups x 1024 threads keep G in LDS, rows dealt cyclically (row i -> workgroup i % 16,
-//      128 KiB each at n = 512), so every step's mat-vec and rank-2 update run out of LDS on 16 CUs.
-//      Two inter-workgroup hand-offs per column (the reflector, then the slices of p = tau A v) use the
-//      write-through form of the guide's inter-workgroup protocol: payload stored and loaded with
-//      agent-scope relaxed atomics (global_store/load ... sc1), every storing wave drains vmcnt,
-//      workgroup barrier, ONE lane publishes a step number / bumps a counter; ONE lane polls with
-//      s_sleep and a wall-clock bound, the others wait at a workgroup barrier.  No fences, no
-//      dependence on placement; a timeout raises an error word and every workgroup leaves.
-//   2. symeig_bisect_kernel    all eigenvalues of T by Sturm-count multisection: one wave per
-//      eigenvalue, 64 shifts per pass, 10 passes (65^10 > 2^53).
-//   3. symeig_vectors_kernel   one wave per wanted eigenvector: inverse iteration on T - lambda I
-//      (pivoted tridiagonal LU, as dstein) in LDS, then the reflectors applied in reverse.
-// The caller (pod.py) finishes with a k x k Rayleigh-Ritz step on G, which also repairs clustered
-// eigenvalues, and checks the residual; any failure falls back to... nothing silent: it raises.
+//      32 workgroups x 1024 threads (128 for n > 512) keep G in LDS, rows dealt cyclically (row i ->
+//      workgroup i % 32), so every step's mat-vec and rank-2 update run out of LDS.  ONE inter-workgroup
+//      hand-off per column (the slices of p = tau A v plus the next row, pre-update) in the write-through
+//      form of the guide's inter-workgroup protocol: payload stored and loaded with agent-scope relaxed
+//      atomics (global_store/load ... sc1), every storing wave drains vmcnt, workgroup barrier, ONE lane
+//      bumps a counter; ONE lane polls with s_sleep and a wall-clock bound, the others wait at a
+//      workgroup barrier.  No fences, no dependence on placement; a timeout raises an error word and
+//      every workgroup leaves.
+//   2. symeig_bisect_kernel    eigenvalues of T by Sturm-count multisection: two waves per eigenvalue,
+//      257 sections per pass, 7 passes (257^7 > 2^53).
+//   3. symeig_wy_kernel + symeig_vectors_kernel   one wave per wanted eigenvector: inverse iteration on
+//      T - lambda I (pivoted tridiagonal LU, as dstein) in LDS, then the reflectors applied in reverse,
+//      four per reduction round.
+// The caller (pod.py) adds a k x k Rayleigh-Ritz step on G when kept eigenvalues are clustered, which also
+// cross-checks the Ritz values against the multisection eigenvalues; a mismatch raises (nothing silent).
 #include "common.h"
 #include "wave_ops.h"
 
@@ -87,7 +88,7 @@ __device__ __forceinline__ double block_sum(double x, double* s_red) {
 // k+1 publishes that row as it stands BEFORE the rank-2 update of step k; after the hand-off every
 // workgroup applies the update to its copy and derives the next reflector redundantly (and, the
 // arithmetic being identical, bit-identically).  All O(n) vector work of a step (reflector, p.v, w, the
-// look-ahead row) is done by wave 0 alone in registers with shuffle reductions - 8 elements per lane -
+// look-ahead row) is done by wave 0 alone in registers with DPP reductions - NM / 64 elements per lane -
 // so a step costs four workgroup barriers; the other 15 waves only do the O(n^2/P) mat-vec and update.
 template <int NM>
 __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
