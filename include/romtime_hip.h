@@ -51,6 +51,10 @@ int rt_last_launch_info(rt_ctx* ctx, int64_t* info3);
  * reduction) with hipEvents on the ctx stream; rt_last_gemm_ms synchronises on the second event
  * and returns that kernel's duration in milliseconds. */
 int rt_ctx_set_profile(rt_ctx* ctx, int on);
+/* Named switches.  "eig_one_xcd" (default 1): the small eigensolver may place its cooperating workgroups on one
+ * XCD and hand off through that XCD's L2 (placement is verified on the device); it needs every CU of that XCD,
+ * so processes that share a GPU turn it off (a hand-off timeout of rt_sym_eig_values is the symptom). */
+int rt_ctx_set_option(rt_ctx* ctx, const char* name, int value);
 int rt_last_gemm_ms(rt_ctx* ctx, double* ms);
 
 /* ---- POD (src/romtime/rom/pod.py:7-62) ------------------------------------------------ */

@@ -31,6 +31,7 @@ SIGNATURES = {
     "rt_last_error": (C.c_char_p, [_p]),
     "rt_last_launch_info": (_int, [_p, C.POINTER(_i64)]),
     "rt_ctx_set_profile": (_int, [_p, _int]),
+    "rt_ctx_set_option": (_int, [_p, C.c_char_p, _int]),
     "rt_last_gemm_ms": (_int, [_p, C.POINTER(C.c_double)]),
     "rt_gram": (_int, [_p, _p, _i64, _i64, _i64, _int, _p]),
     "rt_gram_scale": (_int, [_p, _p, _i64, _p, _int, _p]),
@@ -145,6 +146,9 @@ class Context:
             msg = self.lib.rt_last_error(self.handle)
             raise RomtimeHipError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
         return rc
+
+    def set_option(self, name: str, value: int):
+        self.check(self.lib.rt_ctx_set_option(self.handle, name.encode(), int(value)), "rt_ctx_set_option")
 
     def set_profile(self, on: bool):
         self.profiling = bool(on)

@@ -206,6 +206,17 @@ int rt_last_launch_info(rt_ctx* ctx, int64_t* info3) {
   return RT_OK;
 }
 
+int rt_ctx_set_option(rt_ctx* ctx, const char* name, int value) {
+  if (!ctx || !name) return RT_ERR_ARG;
+  const std::string key(name);
+  if (key == "eig_one_xcd") {
+    ctx->eig_one_xcd = value != 0;
+    return RT_OK;
+  }
+  ctx->err = "rt_ctx_set_option: unknown option " + key;
+  return RT_ERR_ARG;
+}
+
 int rt_ctx_set_profile(rt_ctx* ctx, int on) {
   if (!ctx) return RT_ERR_ARG;
   ctx->profile = (on != 0);

@@ -19,6 +19,7 @@ struct rt_ctx {
   bool profile = false;             // bracket the main GEMM kernel with events (rt_ctx_set_profile)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool ev_valid = false;
+  bool eig_one_xcd = true;          // allow the one-XCD form of the eigensolver's hand-off (rt_ctx_set_option)
   // state handed from rt_sym_eig_values to rt_sym_eig_vectors (pointers into the composite arena)
   struct {
     const double *d = nullptr, *e = nullptr, *V = nullptr, *tau = nullptr;

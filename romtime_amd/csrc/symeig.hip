@@ -18,6 +18,8 @@
 //      four per reduction round.
 // The caller (pod.py) adds a k x k Rayleigh-Ritz step on G when kept eigenvalues are clustered, which also
 // cross-checks the Ritz values against the multisection eigenvalues; a mismatch raises (nothing silent).
+#include <cstdlib>
+
 #include "common.h"
 #include "wave_ops.h"
 
@@ -41,13 +43,30 @@ struct TriParams {
   double* tau;       // n
   double* d;         // n
   double* e;         // n
-  int* flags;        // [1] = arrival counter of the hand-offs, [3] = error
+  int* flags;        // [1] = arrival counter of the hand-offs, [2] = the same for the one-XCD form, [3] = error,
+                     // [8 .. 8 + tw) = XCC id of each workgroup
   int n;
   int tw;            // cooperating workgroups
+  int spread;        // 1: launched as 8 tw blocks, only the blocks with blockIdx % 8 == 0 work (they share an XCD)
 };
 
 __device__ __forceinline__ void st_wt(double* p, double v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// One-XCD form of the hand-off (every cooperating workgroup was SEEN to run on the same XCD, see the kernel): a
+// plain store leaves the line in that XCD's L2, where the sc1 loads of the readers (L1-bypassing, L2-served) find
+// it, and an atomic without sc1 executes in that L2 - a leg costs an L2 round trip instead of a memory-side one.
+__device__ __forceinline__ void st_xcd(double* p, double v, bool one_xcd) {
+  if (one_xcd)
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // a plain global_store
+  else
+    st_wt(p, v);
+}
+__device__ __forceinline__ void arrive(int* flags, bool one_xcd) {
+  if (one_xcd)
+    __hip_atomic_fetch_add(&flags[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  else
+    __hip_atomic_fetch_add(&flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ double ld_wt(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -93,7 +112,9 @@ __device__ __forceinline__ double block_sum(double x, double* s_red) {
 template <int NM>
 __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int n = p.n, TW = p.tw, tid = threadIdx.x, wg = blockIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (p.spread && (blockIdx.x & 7)) return;  // filler blocks: only there to put the workers on one XCD
+  const int n = p.n, TW = p.tw, tid = threadIdx.x, wg = p.spread ? blockIdx.x >> 3 : blockIdx.x, lane = tid & 63,
+            wid = tid >> 6;
   const int RB = (n + TW - 1) / TW;
   double* A = sm;                 // RB x n, local row li <-> global row li*TW + wg
   double* svb = sm + (size_t)RB * n;  // v, double buffered by step parity (2 x n)
@@ -117,13 +138,28 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
   double* L0 = p.P + (size_t)3 * n;
   if (wg == 0)
     for (int j = tid; j < n; j += TT) st_wt(&L0[j], A[j]);
+  if (tid == 0)  // where this workgroup runs: HW_REG_XCC_ID[3:0]
+    __hip_atomic_store(&p.flags[8 + wg], (int)__builtin_amdgcn_s_getreg((4 - 1) << 11 | (0 << 6) | 20) + 1,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid == 0) __hip_atomic_fetch_add(&p.flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) arrive(p.flags, false);
   ++hop;
   if (!wait_flag(&p.flags[1], hop * TW, &p.flags[3], &s_abort)) return;
   for (int j = tid; j < n; j += TT) sl[j] = ld_wt(&L0[j]);
+  // every workgroup reads the same TW ids and takes the same decision; the placement is observed, not assumed
+  __shared__ int s_one;
+  if (tid == 0) {
+    const int mine = __hip_atomic_load(&p.flags[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int same = (p.spread != 0) && (mine > 0);
+    for (int w = 1; w < TW; ++w)
+      same &= (__hip_atomic_load(&p.flags[8 + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine);
+    s_one = same;
+  }
   __syncthreads();
+  const bool one_xcd = s_one != 0;
+  int* const counter = one_xcd ? &p.flags[2] : &p.flags[1];
+  if (one_xcd) hop = 0;  // the one-XCD counter starts from zero
 
   double v[PER];  // wave 0: the reflector of the current step, element j = k + 1 + lane + 64 q
   for (int k = 0; k + 2 < n; ++k) {
@@ -179,19 +215,19 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
           double acc = 0.0;
           for (int j = k + 1 + tx; j < n; j += LPR) acc = fma(row[j], sv[j], acc);
           acc = rtw::wave_sum(acc);
-          if (tx == 0) st_wt(&Pk[gi], tau * acc);
+          if (tx == 0) st_xcd(&Pk[gi], tau * acc, one_xcd);
         }
         if (gi == k + 1)
-          for (int j = k + 1 + tx; j < n; j += LPR) st_wt(&Lk[j], row[j]);
+          for (int j = k + 1 + tx; j < n; j += LPR) st_xcd(&Lk[j], row[j], one_xcd);
       }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // B2
     // one monotonic counter: nobody can arrive for hop h+1 before all arrived for hop h, and the payload
     // buffers alternate, so a fast workgroup never overwrites what a slow one still reads
-    if (tid == 0) __hip_atomic_fetch_add(&p.flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) arrive(p.flags, one_xcd);
     ++hop;
-    if (!wait_flag(&p.flags[1], hop * TW, &p.flags[3], &s_abort)) return;  // B3 inside
+    if (!wait_flag(counter, hop * TW, &p.flags[3], &s_abort)) return;  // B3 inside
     if (wid == 0) {
       // wave 0 takes p and the next row straight into registers
       double pv[PER], lv[PER];
@@ -270,7 +306,7 @@ __device__ __forceinline__ int sturm_count(const double* d, const double* e2, in
 }
 
 __global__ void symeig_init_kernel(int* flags, double* tau, int n) {
-  for (int i = threadIdx.x; i < 8; i += blockDim.x) flags[i] = 0;
+  for (int i = threadIdx.x; i < 8 + 128; i += blockDim.x) flags[i] = 0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) tau[i] = 0.0;
 }
 
@@ -558,13 +594,18 @@ extern "C" int rt_sym_eig_values_part(rt_ctx* ctx, const double* G, int64_t n, i
   size_t off = 0;
   auto take = [&off](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   const size_t oV = take(sizeof(double) * n * n), oP = take(sizeof(double) * 4 * n), oT = take(sizeof(double) * n),
-               oD = take(sizeof(double) * n), oE = take(sizeof(double) * n), oF = take(sizeof(int) * 8);
+               oD = take(sizeof(double) * n), oE = take(sizeof(double) * n), oF = take(sizeof(int) * (8 + 128));
   void* base = nullptr;
   int rc = rt_scratch2(ctx, off, &base);
   if (rc != RT_OK) return rc;
   char* b8 = static_cast<char*>(base);
   TriParams tp;
   tp.G = G; tp.n = (int)n; tp.tw = tw;
+  // n <= 512: launch 8 x 32 blocks and let only every 8th work; blocks b and b + 8 go to the same XCD, so the 32
+  // workers can hand off through one L2 (the kernel checks HW_REG_XCC_ID and falls back to the general form).
+  // ROMTIME_EIG_FLAGS=1 disables it.
+  static const int eig_flags = [] { const char* e = getenv("ROMTIME_EIG_FLAGS"); return e ? atoi(e) : 0; }();
+  tp.spread = (!large && ctx->eig_one_xcd && !(eig_flags & 1) && ctx->num_cus / 8 >= tw) ? 1 : 0;  // a CU per worker
   tp.V = reinterpret_cast<double*>(b8 + oV); tp.P = reinterpret_cast<double*>(b8 + oP);
   tp.tau = reinterpret_cast<double*>(b8 + oT); tp.d = reinterpret_cast<double*>(b8 + oD);
   tp.e = reinterpret_cast<double*>(b8 + oE); tp.flags = reinterpret_cast<int*>(b8 + oF);
@@ -588,7 +629,7 @@ extern "C" int rt_sym_eig_values_part(rt_ctx* ctx, const double* G, int64_t n, i
     hipLaunchKernelGGL(symeig_bisect_kernel<1024>, bgrid, dim3(256), 0, st, tp.d, tp.e, (int)n, (int)first, (int)count,
                        lam, tp.flags, status);
   } else {
-    hipLaunchKernelGGL(symeig_tridiag_kernel<512>, dim3(tw), dim3(TT), lds, st, tp);
+    hipLaunchKernelGGL(symeig_tridiag_kernel<512>, dim3(tp.spread ? 8 * tw : tw), dim3(TT), lds, st, tp);
     RT_HIP_CHECK(ctx, hipGetLastError());
     hipLaunchKernelGGL(symeig_bisect_kernel<512>, bgrid, dim3(256), 0, st, tp.d, tp.e, (int)n, (int)first, (int)count,
                        lam, tp.flags, status);

@@ -120,6 +120,8 @@ class _SmallEig:
     (rt_sym_eig_values / rt_sym_eig_vectors, Rayleigh-Ritz polish on G when kept eigenvalues are
     closer than RR_GAP * lam_1); other sizes use host LAPACK."""
 
+    _retried_general_form = False
+
     def __init__(self, G: torch.Tensor, extra=(), group=None):
         self.G, self.n = G, G.shape[0]
         self.on_device = bool(G.is_cuda and DEVICE_EIG and 3 <= self.n <= DEVICE_EIG_MAX_N)
@@ -141,6 +143,13 @@ class _SmallEig:
             head = torch.cat([self.lam_d, status.to(torch.float64)] + [e.to(torch.float64).reshape(-1) for e in extra])
             head = head.cpu().numpy()  # the one device->host transfer of the step
             self.lam, self.extra = head[: self.n], head[self.n + 1:]
+            if int(head[self.n]) != 0 and not _SmallEig._retried_general_form:
+                # the one-XCD form needs every CU of one XCD; something else held some (another process on this
+                # GPU): switch this context to the general form for good and redo the decomposition once
+                _SmallEig._retried_general_form = True
+                _lib.Context.current().set_option("eig_one_xcd", 0)
+                self.__init__(G, extra=extra, group=group)
+                return
             if int(head[self.n]) != 0:
                 raise _lib.RomtimeHipError("rt_sym_eig_values: inter-workgroup hand-off timed out")
         else:
