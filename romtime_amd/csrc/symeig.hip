@@ -26,6 +26,7 @@
 namespace {
 
 constexpr int TW_SMALL = 32;   // workgroups of the tridiagonalisation, n <= 512 (rows dealt cyclically)
+constexpr int SLOT0 = 160;     // first arrival slot in the flag words (128-byte aligned)
 constexpr int TW_LARGE = 128;  // 512 < n <= 1024: 8 rows of 1024 per workgroup
 constexpr int LPR = 64;     // lanes per matrix row in the mat-vec / rank-2 update (TT / LPR rows per pass)
 constexpr int TT = 1024;    // threads per workgroup
@@ -43,8 +44,7 @@ struct TriParams {
   double* tau;       // n
   double* d;         // n
   double* e;         // n
-  int* flags;        // [1] = arrival counter of the hand-offs, [2] = the same for the one-XCD form, [3] = error,
-                     // [8 .. 8 + tw) = XCC id of each workgroup
+  int* flags;        // [3] = error, [8 .. 8 + tw) = XCC id of each workgroup, [SLOT0 .. SLOT0 + tw) = arrival slots
   int n;
   int tw;            // cooperating workgroups
   int spread;        // 1: launched as 8 tw blocks, only the blocks with blockIdx % 8 == 0 work (they share an XCD)
@@ -55,41 +55,44 @@ __device__ __forceinline__ void st_wt(double* p, double v) {
 }
 // One-XCD form of the hand-off (every cooperating workgroup was SEEN to run on the same XCD, see the kernel): a
 // plain store leaves the line in that XCD's L2, where the sc1 loads of the readers (L1-bypassing, L2-served) find
-// it, and an atomic without sc1 executes in that L2 - a leg costs an L2 round trip instead of a memory-side one.
+// it - a leg costs an L2 round trip instead of a memory-side one.
 __device__ __forceinline__ void st_xcd(double* p, double v, bool one_xcd) {
   if (one_xcd)
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);  // a plain global_store
   else
     st_wt(p, v);
 }
-__device__ __forceinline__ void arrive(int* flags, bool one_xcd) {
+__device__ __forceinline__ void st_slot(int* p, int v, bool one_xcd) {
   if (one_xcd)
-    __hip_atomic_fetch_add(&flags[2], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
   else
-    __hip_atomic_fetch_add(&flags[1], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ double ld_wt(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// lane 0 of the workgroup waits until *flag >= want (or the error word is set / 2 s pass)
-__device__ __forceinline__ bool wait_flag(int* flag, int want, int* err, int* s_abort) {
-  if (threadIdx.x == 0) {
-    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
-    int bad = 0;
-    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-      __builtin_amdgcn_s_sleep(2);
-      if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) { bad = 1; break; }
-      if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
-        __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bad = 1;
-        break;
-      }
+// Arrival at a hand-off = storing the hop number into the workgroup's own slot; one wave waits until every slot
+// holds >= want (the TW slots are one or two 128-byte lines: one load per poll, and no read-modify-write that 32
+// arrivals would queue up behind - a shared counter cost 0.6 us per hop more).  Called by a whole wave; false if
+// the error word is set or 2 s pass.
+__device__ __forceinline__ bool poll_slots(int* slots, int TW, int want, int* err) {
+  const int lane = threadIdx.x & 63;
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
+  for (;;) {
+    int f = want;
+    for (int w = lane; w < TW; w += 64) {
+      const int g = __hip_atomic_load(&slots[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      f = g < f ? g : f;
     }
-    *s_abort = bad;
+    if (__builtin_amdgcn_ballot_w64(f < want) == 0) return true;
+    __builtin_amdgcn_s_sleep(1);
+    if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+      __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return false;
+    }
   }
-  __syncthreads();
-  return *s_abort == 0;
 }
 
 __device__ __forceinline__ double block_sum(double x, double* s_red) {
@@ -121,6 +124,7 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
   double* sw = svb + 2 * n;
   double* sl = sw + n;            // current row k (entries j >= k), maintained by wave 0
   __shared__ int s_abort;
+  if (threadIdx.x == 0) s_abort = 0;
   __shared__ double s_tau;
   constexpr int PER = NM / 64;
 
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
   }
   __syncthreads();
   const int ty = tid / LPR, tx = tid % LPR;  // (TT / LPR) rows x LPR lanes; with LPR = 64: ty == wave id
-  int hop = 0;                                // counter target is hop * TW
+  int hop = 0;                                // hand-offs so far
 
   // step "-1": row 0 to everybody
   // P = [p even | p odd | row even | row odd].  Row 0 travels in the ODD row buffer: step 0 stores into the even
@@ -143,9 +147,13 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (tid == 0) arrive(p.flags, false);
   ++hop;
-  if (!wait_flag(&p.flags[1], hop * TW, &p.flags[3], &s_abort)) return;
+  if (wid == 0) {
+    if (lane == 0) st_slot(&p.flags[SLOT0 + wg], hop, false);
+    if (!poll_slots(&p.flags[SLOT0], TW, hop, &p.flags[3]) && lane == 0) s_abort = 1;
+  }
+  __syncthreads();
+  if (s_abort) return;
   for (int j = tid; j < n; j += TT) sl[j] = ld_wt(&L0[j]);
   // every workgroup reads the same TW ids and takes the same decision; the placement is observed, not assumed
   __shared__ int s_one;
@@ -158,8 +166,6 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
   }
   __syncthreads();
   const bool one_xcd = s_one != 0;
-  int* const counter = one_xcd ? &p.flags[2] : &p.flags[1];
-  if (one_xcd) hop = 0;  // the one-XCD counter starts from zero
 
   double v[PER];  // wave 0: the reflector of the current step, element j = k + 1 + lane + 64 q
   for (int k = 0; k + 2 < n; ++k) {
@@ -223,12 +229,14 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // B2
-    // one monotonic counter: nobody can arrive for hop h+1 before all arrived for hop h, and the payload
-    // buffers alternate, so a fast workgroup never overwrites what a slow one still reads
-    if (tid == 0) arrive(p.flags, one_xcd);
+    // the hop numbers only grow: nobody can arrive for hop h+1 before all arrived for hop h, and the payload
+    // buffers alternate, so a fast workgroup never overwrites what a slow one still reads.  Wave 0 arrives, waits
+    // and goes straight on to the payload; the other waves meet it again at B5.
     ++hop;
-    if (!wait_flag(counter, hop * TW, &p.flags[3], &s_abort)) return;  // B3 inside
-    if (wid == 0) {
+    if (wid == 0 && lane == 0) st_slot(&p.flags[SLOT0 + wg], hop, one_xcd);
+    if (wid == 0 && !poll_slots(&p.flags[SLOT0], TW, hop, &p.flags[3])) {
+      if (lane == 0) s_abort = 1;
+    } else if (wid == 0) {
       // wave 0 takes p and the next row straight into registers
       double pv[PER], lv[PER];
 #pragma unroll
@@ -263,6 +271,7 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
       }
     }
     __syncthreads();  // B5: sw, sl
+    if (s_abort) return;
     if (tau == 0.0) continue;
     // ---- A <- A - v w^T - w v^T on the local rows i > k (each wave touches only the rows it also reads) ----
     for (int li = ty; li < RB; li += TT / LPR) {
@@ -306,7 +315,7 @@ __device__ __forceinline__ int sturm_count(const double* d, const double* e2, in
 }
 
 __global__ void symeig_init_kernel(int* flags, double* tau, int n) {
-  for (int i = threadIdx.x; i < 8 + 128; i += blockDim.x) flags[i] = 0;
+  for (int i = threadIdx.x; i < SLOT0 + TW_LARGE; i += blockDim.x) flags[i] = 0;
   for (int i = threadIdx.x; i < n; i += blockDim.x) tau[i] = 0.0;
 }
 
@@ -585,6 +594,7 @@ extern "C" int rt_sym_eig_values_part(rt_ctx* ctx, const double* G, int64_t n, i
     return RT_ERR_UNSUPPORTED;
   }
   const bool large = n > 512;
+  static const int eig_flags = [] { const char* e = getenv("ROMTIME_EIG_FLAGS"); return e ? atoi(e) : 0; }();
   const int tw = large ? TW_LARGE : TW_SMALL;
   if (tw > ctx->num_cus) {  // the cooperating workgroups must all be resident
     ctx->err = "rt_sym_eig_values: not enough compute units for the cooperative tridiagonalisation";
@@ -594,7 +604,7 @@ extern "C" int rt_sym_eig_values_part(rt_ctx* ctx, const double* G, int64_t n, i
   size_t off = 0;
   auto take = [&off](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   const size_t oV = take(sizeof(double) * n * n), oP = take(sizeof(double) * 4 * n), oT = take(sizeof(double) * n),
-               oD = take(sizeof(double) * n), oE = take(sizeof(double) * n), oF = take(sizeof(int) * (8 + 128));
+               oD = take(sizeof(double) * n), oE = take(sizeof(double) * n), oF = take(sizeof(int) * (SLOT0 + TW_LARGE));
   void* base = nullptr;
   int rc = rt_scratch2(ctx, off, &base);
   if (rc != RT_OK) return rc;
@@ -604,7 +614,6 @@ extern "C" int rt_sym_eig_values_part(rt_ctx* ctx, const double* G, int64_t n, i
   // n <= 512: launch 8 x 32 blocks and let only every 8th work; blocks b and b + 8 go to the same XCD, so the 32
   // workers can hand off through one L2 (the kernel checks HW_REG_XCC_ID and falls back to the general form).
   // ROMTIME_EIG_FLAGS=1 disables it.
-  static const int eig_flags = [] { const char* e = getenv("ROMTIME_EIG_FLAGS"); return e ? atoi(e) : 0; }();
   tp.spread = (!large && ctx->eig_one_xcd && !(eig_flags & 1) && ctx->num_cus / 8 >= tw) ? 1 : 0;  // a CU per worker
   tp.V = reinterpret_cast<double*>(b8 + oV); tp.P = reinterpret_cast<double*>(b8 + oP);
   tp.tau = reinterpret_cast<double*>(b8 + oT); tp.d = reinterpret_cast<double*>(b8 + oD);
