@@ -37,6 +37,9 @@ RR_GAP = 1e-4           # smallest eigenvalue gap (relative to lam_1) for which 
 TWO_PASS_RATIO = 1e-2  # one Gram pass: vectors good to ~eps (sigma_1/sigma_i)^2 <= 2e-12 above this ratio
 
 
+# shapes (n, num, normalize) whose last POD could not use the work enqueued ahead of the eigenvalues (pod_device)
+_AHEAD_DROPPED: dict = {}
+
 # stage timings of the most recent pod_device call (host wall clock, ms); filled only when the
 # ctx is in profile mode (rt_ctx_set_profile), which bench.py switches on for its timed region
 LAST_TIMINGS: dict = {}
@@ -122,10 +125,13 @@ class _SmallEig:
 
     _retried_general_form = False
 
-    def __init__(self, G: torch.Tensor, extra=(), group=None):
+    def __init__(self, G: torch.Tensor, extra=(), group=None, ahead=None):
+        """``ahead(self)``: device work the caller wants enqueued BEFORE the eigenvalues reach the host (it may
+        use ``raw_vectors``); the eigenvalues then travel on a side stream while that work runs."""
         self.G, self.n = G, G.shape[0]
         self.on_device = bool(G.is_cuda and DEVICE_EIG and 3 <= self.n <= DEVICE_EIG_MAX_N)
         self.group = group if (group is not None and self.on_device and _world(group) > 1) else None
+        self._raw = {}
         if self.on_device:
             if self.group is None:
                 self.lam_d, status = ops.sym_eig_values(G)
@@ -141,14 +147,17 @@ class _SmallEig:
                     self.lam_d[f:f + cnt] = piece[:cnt]
                 status = torch.stack([piece[cnt] for piece in pieces]).max().reshape(1)
             head = torch.cat([self.lam_d, status.to(torch.float64)] + [e.to(torch.float64).reshape(-1) for e in extra])
-            head = head.cpu().numpy()  # the one device->host transfer of the step
+            if ahead is None:
+                head = head.cpu().numpy()  # the one device->host transfer of the step
+            else:
+                head = _fetch_beside(head, lambda: ahead(self))
             self.lam, self.extra = head[: self.n], head[self.n + 1:]
             if int(head[self.n]) != 0 and not _SmallEig._retried_general_form:
                 # the one-XCD form needs every CU of one XCD; something else held some (another process on this
                 # GPU): switch this context to the general form for good and redo the decomposition once
                 _SmallEig._retried_general_form = True
                 _lib.Context.current().set_option("eig_one_xcd", 0)
-                self.__init__(G, extra=extra, group=group)
+                self.__init__(G, extra=extra, group=group, ahead=ahead)
                 return
             if int(head[self.n]) != 0:
                 raise _lib.RomtimeHipError("rt_sym_eig_values: inter-workgroup hand-off timed out")
@@ -156,6 +165,31 @@ class _SmallEig:
             Gh = G.cpu().numpy()
             self.extra = np.concatenate([np.atleast_1d(e.cpu().numpy()).astype(float) for e in extra]) if extra else np.zeros(0)
             self.lam, self.W = _eigh_desc(Gh)
+
+    def raw_vectors(self, k: int) -> torch.Tensor:
+        """Inverse-iteration eigenvectors of the k largest eigenvalues as the device computes them (no host data
+        needed: usable before the eigenvalues have been fetched).  Cached per k."""
+        if k in self._raw:
+            return self._raw[k]
+        if self.group is None:
+            Z = ops.sym_eig_vectors(self.lam_d, k)
+        else:  # each rank back-transforms its share of the k vectors
+            first, cnt = _share(k, self.group)
+            pieces = _allgather(ops.sym_eig_vectors(self.lam_d, cnt, first=first), self.group)
+            Z = torch.empty((self.n, k), dtype=torch.float64, device=self.G.device)
+            for r, piece in enumerate(pieces):
+                f, _ = _share(k, self.group, rank=r)
+                Z[:, f:f + cnt] = piece
+        self._raw[k] = Z
+        return Z
+
+    def well_separated(self, k: int) -> bool:
+        """Inverse iteration resolves an eigenvector to ~eps ||G|| / gap: with every gap among the kept
+        eigenvalues (and to the first discarded one) above RR_GAP * lam_1 that is <= 2e-12 and the
+        vectors are used as they are; closer eigenvalues get a k x k Rayleigh-Ritz step on G (``vectors``)."""
+        n, lam = self.n, self.lam
+        gaps = lam[:k] - lam[1:k + 1] if k < n else np.r_[lam[:k - 1] - lam[1:k], lam[k - 1]]
+        return bool(gaps.min() >= RR_GAP * max(lam[0], 1e-300))
 
     def vectors(self, k: int) -> torch.Tensor:
         """n x k eigenvectors of the k largest eigenvalues (must be called before any other device
@@ -165,20 +199,8 @@ class _SmallEig:
         n, lam = self.n, self.lam
         if not self.on_device:
             return ops.to_device(np.ascontiguousarray(self.W[:, :k]), self.G.device)
-        if self.group is None:
-            Z = ops.sym_eig_vectors(self.lam_d, k)
-        else:  # each rank back-transforms its share of the k vectors
-            first, cnt = _share(k, self.group)
-            pieces = _allgather(ops.sym_eig_vectors(self.lam_d, cnt, first=first), self.group)
-            Z = torch.empty((n, k), dtype=torch.float64, device=self.G.device)
-            for r, piece in enumerate(pieces):
-                f, _ = _share(k, self.group, rank=r)
-                Z[:, f:f + cnt] = piece
-        # inverse iteration resolves an eigenvector to ~eps ||G|| / gap: with every gap among the kept
-        # eigenvalues (and to the first discarded one) above RR_GAP * lam_1 that is <= 2e-12 and the
-        # vectors are used as they are; closer eigenvalues get a k x k Rayleigh-Ritz step on G
-        gaps = lam[:k] - lam[1:k + 1] if k < n else np.r_[lam[:k - 1] - lam[1:k], lam[k - 1]]
-        if gaps.min() >= RR_GAP * max(lam[0], 1e-300):
+        Z = self.raw_vectors(k)
+        if self.well_separated(k):
             return Z
         GZ = ops.gemm_nn(self.G, Z)
         HS = torch.cat([ops.gemm_tn(Z, GZ), ops.gemm_tn(Z, Z)], dim=0).cpu().numpy()
@@ -189,6 +211,31 @@ class _SmallEig:
         if np.abs(theta - lam[:k]).max() > 1e-9 * max(lam[0], 1e-300):
             raise _lib.RomtimeHipError("device eigenvectors failed the Rayleigh-Ritz cross-check")
         return ops.gemm_nn(Z, ops.to_device(C, Z.device))
+
+
+_PINNED: dict = {}
+
+
+def _fetch_beside(head: torch.Tensor, enqueue) -> np.ndarray:
+    """Bring ``head`` to the host on a side stream while the work ``enqueue()`` puts on the current stream runs:
+    the transfer does not queue behind that work, and the host reads the result while the device is busy."""
+    dev = head.device
+    main = torch.cuda.current_stream(dev)
+    key = (dev.index, head.numel())
+    if key not in _PINNED:
+        _PINNED[key] = (torch.empty(head.numel(), dtype=torch.float64).pin_memory(), torch.cuda.Stream(dev))
+    pinned, side = _PINNED[key]
+    ready = torch.cuda.Event()
+    ready.record(main)
+    head.record_stream(side)
+    with torch.cuda.stream(side):
+        side.wait_event(ready)
+        pinned.copy_(head, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(side)
+    enqueue()
+    done.synchronize()
+    return pinned.numpy().copy()
 
 
 def _world(group):
@@ -256,7 +303,26 @@ def pod_device(X: torch.Tensor, num=None, tol=None, normalize=True, passes=None,
     if prof:
         ev[1].record()  # the current stream waits for the collective, so this event closes Gram + all-reduce
     colnorm, flag = ops.gram_scale(G, normalize)
-    eig = _SmallEig(G, extra=(flag, Gbuf[n * n:]), group=group)
+    # ``num`` alone fixes the number of modes before any eigenvalue is known (pod.py:51-53): the eigenvectors and
+    # the back-projection of a single-pass POD are then enqueued right behind the eigenvalue kernels, and the
+    # host reads the eigenvalues (for sigma, the energy curve and the checks below) while they run.  If the
+    # checks say the spectrum needs the deflated route or a Rayleigh-Ritz step, that result is dropped.
+    k_ahead = int(min(num, n)) if (num and not tol and passes in (None, 1) and X.is_cuda) else 0  # same on every rank
+    ahead_key = (n, k_ahead, bool(normalize))
+    if _AHEAD_DROPPED.get(ahead_key):
+        k_ahead = 0  # the last POD of this shape needed the deflated route: do not enqueue work that is thrown away
+    ahead_out = {}
+
+    def ahead(e):
+        if not e.on_device or k_ahead < 1:
+            return
+        Z = e.raw_vectors(k_ahead)
+        sig = e.lam_d[:k_ahead].clamp_min(0.0).sqrt()
+        inv = torch.where(sig > 0, 1.0 / sig, torch.zeros_like(sig))
+        Zs = (Z / colnorm[:, None] if normalize else Z) * inv[None, :]
+        ahead_out["Q"] = ops.gemm_nn(X, Zs.contiguous())
+
+    eig = _SmallEig(G, extra=(flag, Gbuf[n * n:]), group=group, ahead=ahead if k_ahead else None)
     t1 = time.perf_counter()
     if normalize and int(eig.extra[0]) != 0:
         # the reference divides by a zero norm and scipy.linalg.svd then rejects the NaNs (pod.py:32-38)
@@ -268,9 +334,13 @@ def pod_device(X: torch.Tensor, num=None, tol=None, normalize=True, passes=None,
     deep = r > 0 and s[0] > 0 and s[r - 1] < TWO_PASS_RATIO * s[0]
     if passes is None:
         passes = "deflate" if deep else 1
+    _AHEAD_DROPPED[ahead_key] = bool(passes != 1 or r != ahead_key[1])
 
     if passes == 1:
-        if r > 0:
+        if r > 0 and r == k_ahead and "Q" in ahead_out and eig.well_separated(r):
+            Q = ahead_out["Q"]  # enqueued before the eigenvalues arrived, and they confirm it
+            VT = np.ascontiguousarray(eig.raw_vectors(r).cpu().numpy().T) if want_vt else None
+        elif r > 0:
             Z = eig.vectors(r)
             Zs = (Z / colnorm[:, None] if normalize else Z) * ops.to_device(_inv_or_zero(s[:r]), X.device)[None, :]
             Q = ops.gemm_nn(X, Zs.contiguous())

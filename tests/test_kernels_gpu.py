@@ -312,3 +312,33 @@ def test_gemm_nn_accumulate(ops, N, n, k):
     Y = ops.to_device(np.full((N, k), np.nan))          # beta == 0: the output is not read
     ops.gemm_nn(ops.to_device(X), ops.to_device(T), out=Y)
     assert _rel(Y.cpu().numpy(), X @ T) < 5e-14
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("decay,expect_ahead", [(1.0, True), (9.0, False)])
+def test_pod_work_enqueued_ahead_of_the_eigenvalues(ops, decay, expect_ahead):
+    """orth(num=...) enqueues eigenvectors + back-projection before the eigenvalues reach the host; the host
+    checks decide afterwards whether that result stands (shallow spectrum) or is dropped (deep spectrum ->
+    deflated levels).  Either way the outcome equals the route taken without looking ahead, and dgesvd."""
+    from romtime_amd import pod
+
+    rng = np.random.RandomState(11)
+    N, n, k = 6000, 96, 12
+    U, _ = np.linalg.qr(rng.standard_normal((N, n)))
+    V, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    X = (U * 10.0 ** (-decay * np.arange(n) / (n - 1) * (n - 1) / (k - 1))) @ V.T   # sigma_k / sigma_1 = 10^-decay
+    Xd = ops.to_device(X)
+    key = (n, k, True)
+    pod._AHEAD_DROPPED.pop(key, None)
+    first = pod.pod_device(Xd, num=k, normalize=True)
+    assert pod._AHEAD_DROPPED[key] == (not expect_ahead)
+    assert first["passes"] == (1 if expect_ahead else "deflate")
+    pod._AHEAD_DROPPED[key] = True            # forces the route without look-ahead
+    second = pod.pod_device(Xd, num=k, normalize=True)
+    np.testing.assert_array_equal(first["s"], second["s"])
+    np.testing.assert_allclose(first["Q"].cpu().numpy(), second["Q"].cpu().numpy(), rtol=0, atol=1e-13)
+    Qo, so, _ = oracle.orth(X, num=k, normalize=True)
+    # the POD bar of tests/test_surface.py: 2e-13 sigma_1 + 8 eps sigma_1^2 / sigma_i
+    assert np.all(np.abs(first["s"][:k] - so[:k]) <= 2e-13 * so[0] + 8 * np.finfo(float).eps * so[0] ** 2 / so[:k])
+    Q = first["Q"].cpu().numpy()
+    assert np.abs(np.abs(np.sum(Q * Qo, axis=0)) - 1.0).max() < 1e-9
