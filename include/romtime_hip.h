@@ -56,6 +56,9 @@ int rt_ctx_set_profile(rt_ctx* ctx, int on);
  * so processes that share a GPU turn it off (a hand-off timeout of rt_sym_eig_values is the symptom). */
 int rt_ctx_set_option(rt_ctx* ctx, const char* name, int value);
 int rt_last_gemm_ms(rt_ctx* ctx, double* ms);
+/* The same for the most recent launch of the snapshot Gram kernel (rt_gram, n >= 97, long X): its own event pair,
+ * so it can be read at the end of a POD step, after the GEMMs that followed it, without holding the host back. */
+int rt_last_gram_ms(rt_ctx* ctx, double* ms);
 
 /* ---- POD (src/romtime/rom/pod.py:7-62) ------------------------------------------------ */
 

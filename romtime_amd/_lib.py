@@ -33,6 +33,7 @@ SIGNATURES = {
     "rt_ctx_set_profile": (_int, [_p, _int]),
     "rt_ctx_set_option": (_int, [_p, C.c_char_p, _int]),
     "rt_last_gemm_ms": (_int, [_p, C.POINTER(C.c_double)]),
+    "rt_last_gram_ms": (_int, [_p, C.POINTER(C.c_double)]),
     "rt_gram": (_int, [_p, _p, _i64, _i64, _i64, _int, _p]),
     "rt_gram_scale": (_int, [_p, _p, _i64, _p, _int, _p]),
     "rt_gemm_tn": (_int, [_p, _p, _i64, _int, _p, _i64, _int, _i64, _i64, _i64, _p, _i64]),
@@ -157,6 +158,14 @@ class Context:
     def last_gemm_ms(self) -> float:
         out = C.c_double()
         self.check(self.lib.rt_last_gemm_ms(self.handle, C.byref(out)), "rt_last_gemm_ms")
+        return out.value
+
+    def last_gram_ms(self) -> float:
+        """Duration of the most recent snapshot Gram kernel (gram128 route) in profile mode; NaN if the last Gram
+        took the generic GEMM route."""
+        out = C.c_double()
+        if self.lib.rt_last_gram_ms(self.handle, C.byref(out)) != 0:
+            return float("nan")
         return out.value
 
     def launch_info(self):

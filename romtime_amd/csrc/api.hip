@@ -181,6 +181,8 @@ void rt_ctx_destroy(rt_ctx* ctx) {
   if (ctx->scratch2) (void)hipFree(ctx->scratch2);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->gev0) (void)hipEventDestroy(ctx->gev0);
+  if (ctx->gev1) (void)hipEventDestroy(ctx->gev1);
   delete ctx;
 }
 
@@ -221,6 +223,20 @@ int rt_ctx_set_profile(rt_ctx* ctx, int on) {
   if (!ctx) return RT_ERR_ARG;
   ctx->profile = (on != 0);
   ctx->ev_valid = false;
+  ctx->gev_valid = false;
+  return RT_OK;
+}
+
+int rt_last_gram_ms(rt_ctx* ctx, double* ms) {
+  if (!ctx || !ms) return RT_ERR_ARG;
+  if (!ctx->gev_valid) {
+    ctx->err = "rt_last_gram_ms: no profiled launch of the snapshot Gram kernel recorded";
+    return RT_ERR_ARG;
+  }
+  RT_HIP_CHECK(ctx, hipEventSynchronize(ctx->gev1));
+  float f = 0.f;
+  RT_HIP_CHECK(ctx, hipEventElapsedTime(&f, ctx->gev0, ctx->gev1));
+  *ms = f;
   return RT_OK;
 }
 

@@ -19,6 +19,8 @@ struct rt_ctx {
   bool profile = false;             // bracket the main GEMM kernel with events (rt_ctx_set_profile)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool ev_valid = false;
+  hipEvent_t gev0 = nullptr, gev1 = nullptr;  // the Gram kernel's own pair (rt_last_gram_ms): survives later GEMMs
+  bool gev_valid = false;
   bool eig_one_xcd = true;          // allow the one-XCD form of the eigensolver's hand-off (rt_ctx_set_option)
   // state handed from rt_sym_eig_values to rt_sym_eig_vectors (pointers into the composite arena)
   struct {

@@ -262,7 +262,12 @@ int rt_gram128(rt_ctx* ctx, const double* X, int64_t ks, int64_t ms, int64_t K, 
       RT_HIP_CHECK(ctx, hipEventCreate(&ctx->ev0));
       RT_HIP_CHECK(ctx, hipEventCreate(&ctx->ev1));
     }
+    if (!ctx->gev0) {
+      RT_HIP_CHECK(ctx, hipEventCreate(&ctx->gev0));
+      RT_HIP_CHECK(ctx, hipEventCreate(&ctx->gev1));
+    }
     RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    RT_HIP_CHECK(ctx, hipEventRecord(ctx->gev0, ctx->stream));
   }
   // launch 1: off-diagonal tiles
   if (n_off) {
@@ -298,7 +303,9 @@ int rt_gram128(rt_ctx* ctx, const double* X, int64_t ks, int64_t ms, int64_t K, 
   }
   if (ctx->profile) {
     RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    RT_HIP_CHECK(ctx, hipEventRecord(ctx->gev1, ctx->stream));
     ctx->ev_valid = true;
+    ctx->gev_valid = true;
   }
   ctx->last_grid = 8 * (nslots_off + nslots_diag); ctx->last_splits = 8 * S_off; ctx->last_tile = 128 * 1000 + 128;
   const long total = n * n;

@@ -40,9 +40,30 @@ TWO_PASS_RATIO = 1e-2  # one Gram pass: vectors good to ~eps (sigma_1/sigma_i)^2
 # shapes (n, num, normalize) whose last POD could not use the work enqueued ahead of the eigenvalues (pod_device)
 _AHEAD_DROPPED: dict = {}
 
-# stage timings of the most recent pod_device call (host wall clock, ms); filled only when the
-# ctx is in profile mode (rt_ctx_set_profile), which bench.py switches on for its timed region
+# stage timings of the most recent pod_device call in profile mode (rt_ctx_set_profile, which bench.py switches
+# on for its timed region): pod_device only records events, stage_timings() waits for them and fills this dict
 LAST_TIMINGS: dict = {}
+_PENDING_TIMINGS: dict = {}
+
+
+def stage_timings() -> dict:
+    """Stage durations (ms, device time between stream events) of the most recent profiled ``pod_device`` call."""
+    if _PENDING_TIMINGS:
+        pend = dict(_PENDING_TIMINGS)
+        _PENDING_TIMINGS.clear()
+        ev = pend["ev"]
+        ev[3].synchronize()
+        LAST_TIMINGS.clear()
+        LAST_TIMINGS["gram_kernel_ms"] = pend["gram_kernel_ms"]
+        LAST_TIMINGS["gram_allreduce_ms"] = ev[0].elapsed_time(ev[1])
+        LAST_TIMINGS["scale_eigvals_ms"] = ev[1].elapsed_time(ev[2])
+        LAST_TIMINGS["eigvec_backproject_ms"] = ev[2].elapsed_time(ev[3])
+        LAST_TIMINGS["total_ms"] = ev[0].elapsed_time(ev[3])
+        LAST_TIMINGS["host_enqueue_ms"] = pend["host_ms"]
+        LAST_TIMINGS["eig_on_device"] = pend["eig_on_device"]
+        if pend["levels"] is not None:
+            LAST_TIMINGS["levels"] = pend["levels"]
+    return LAST_TIMINGS
 
 
 def truncation_rank(s, energy, num=None, tol=None) -> int:
@@ -288,17 +309,14 @@ def pod_device(X: torch.Tensor, num=None, tol=None, normalize=True, passes=None,
     ctx = _lib.Context.current() if X.is_cuda else None
     prof = bool(ctx is not None and _profiling(ctx))
     t0 = time.perf_counter()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if prof else None
+    # profile mode: stage boundaries are events on the stream, resolved by stage_timings() - nothing here waits
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if prof else None
     if prof:
         ev[0].record()
     # G and the row count share one buffer, so a row-sharded run needs a single all-reduce
     Gbuf = torch.empty(n * n + 1, dtype=torch.float64, device=X.device)
     G = ops.gram(X, out=Gbuf[: n * n].view(n, n))
     Gbuf[n * n:].fill_(float(X.shape[0]))
-    if prof:
-        LAST_TIMINGS.clear()
-        LAST_TIMINGS["gram_kernel_ms"] = ctx.last_gemm_ms()
-        LAST_TIMINGS["gram_ms"] = 1e3 * (time.perf_counter() - t0)
     _allreduce(Gbuf, group)
     if prof:
         ev[1].record()  # the current stream waits for the collective, so this event closes Gram + all-reduce
@@ -314,6 +332,8 @@ def pod_device(X: torch.Tensor, num=None, tol=None, normalize=True, passes=None,
     ahead_out = {}
 
     def ahead(e):
+        if prof:
+            ev[2].record()  # eigenvalues enqueued; what follows is eigenvectors + back-projection
         if not e.on_device or k_ahead < 1:
             return
         Z = e.raw_vectors(k_ahead)
@@ -323,7 +343,8 @@ def pod_device(X: torch.Tensor, num=None, tol=None, normalize=True, passes=None,
         ahead_out["Q"] = ops.gemm_nn(X, Zs.contiguous())
 
     eig = _SmallEig(G, extra=(flag, Gbuf[n * n:]), group=group, ahead=ahead if k_ahead else None)
-    t1 = time.perf_counter()
+    if prof and not k_ahead:
+        ev[2].record()
     if normalize and int(eig.extra[0]) != 0:
         # the reference divides by a zero norm and scipy.linalg.svd then rejects the NaNs (pod.py:32-38)
         raise ValueError("array must not contain infs or NaNs (zero-norm snapshot with normalize=True)")
@@ -360,7 +381,6 @@ def pod_device(X: torch.Tensor, num=None, tol=None, normalize=True, passes=None,
         VT = np.ascontiguousarray((W.cpu().numpy() @ W2[:, :r]).T) if want_vt else None
     elif passes == "deflate":
         Q, s, energy, r, VT, levels = _pod_deflated(X, eig, colnorm, normalize, num, tol, group, want_vt)
-        LAST_TIMINGS["levels"] = float(levels)
     else:
         raise ValueError(f"passes must be None, 1, 2 or 'deflate', not {passes!r}")
     # more snapshots than DoFs: the thin SVD of the reference has only min(N, n) singular values (pod.py:38)
@@ -370,14 +390,15 @@ def pod_device(X: torch.Tensor, num=None, tol=None, normalize=True, passes=None,
         Q = Q[:, :r].contiguous()
         VT = VT[:r] if VT is not None else None
     if prof:
-        torch.cuda.synchronize()
-        t3 = time.perf_counter()
-        LAST_TIMINGS["allreduce_scale_eigvals_ms"] = 1e3 * (t1 - t0) - LAST_TIMINGS["gram_ms"]
-        LAST_TIMINGS["eigvec_backproject_ms"] = 1e3 * (t3 - t1)
-        LAST_TIMINGS["total_ms"] = 1e3 * (t3 - t0)
-        LAST_TIMINGS["gram_allreduce_ms"] = ev[0].elapsed_time(ev[1])
-        LAST_TIMINGS["eig_on_device"] = float(eig.on_device)
-    return dict(Q=Q, s=s, energy=energy, VT=VT, r=r, passes=passes, colnorm=colnorm)
+        ev[3].record()
+        _PENDING_TIMINGS.clear()
+        _PENDING_TIMINGS.update(ev=ev, gram_kernel_ms=ctx.last_gram_ms(), host_ms=1e3 * (time.perf_counter() - t0),
+                                eig_on_device=float(eig.on_device),
+                                levels=float(levels) if passes == "deflate" else None)
+    out = dict(Q=Q, s=s, energy=energy, VT=VT, r=r, passes=passes, colnorm=colnorm)
+    if prof:
+        out["gram_kernel_ms"] = _PENDING_TIMINGS["gram_kernel_ms"]
+    return out
 
 
 MAX_LEVELS = 12

@@ -11,7 +11,7 @@ for i in range(8):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     out = pod.pod_device(X, num=40, normalize=True)
     torch.cuda.synchronize(); dt = 1e3 * (time.perf_counter() - t0)
-    print(f"step {i}: wall {dt:.2f} ms", {k: round(v, 2) for k, v in pod.LAST_TIMINGS.items()})
+    print(f"step {i}: wall {dt:.2f} ms", {k: round(v, 2) for k, v in pod.stage_timings().items()})
 print("---- allocator probe")
 for i in range(7):
     st0 = torch.cuda.memory_stats()
