@@ -25,5 +25,5 @@ python3 tools/summarize_prof.py ${ROUND}_bench_${TAG} --stats $O/stats --fetch $
 python3 tools/summarize_prof.py ${ROUND}_sweep_${TAG} --stats $O/sweep_stats || exit 10
 python3 tools/summarize_prof.py ${ROUND}_hsweep_${TAG} --stats $O/hsweep_stats || exit 11
 cp profiles/${ROUND}_*_${TAG}* profiles/gram_traffic.json $DEST/
-rm -rf $O/stats $O/fetch $O/write $O/sq $O/sweep_stats $O/hsweep_stats   # raw output is large; the summaries are what is kept
+rm -f $DEST/*_sweep_*_pmc.json $DEST/*_hsweep_*_pmc.json; rm -rf $O/stats $O/fetch $O/write $O/sq $O/sweep_stats $O/hsweep_stats   # raw output is large; the summaries are what is kept
 ls -la $DEST
