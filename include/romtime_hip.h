@@ -91,6 +91,14 @@ int rt_gemm_nn_axpby(rt_ctx* ctx, const double* X, int64_t ldx, int x_layout, co
                      int64_t N, int64_t n, int64_t k, double alpha, double beta, double* Y, int64_t ldy,
                      int y_layout);
 
+/* Thin update of a tall row-major matrix: Y_dst (N x n) = Y_src diag(colscale) + alpha X (N x k) T (k x n), k <= 64
+ * (RT_ERR_UNSUPPORTED above), colscale optional (NULL = 1), Y_src == Y_dst allowed.  The deflation sweep
+ * X <- X - Q (Q^T X) of the levelled POD (romtime_amd/pod.py; replaces what dgesvd's bidiagonalisation does
+ * implicitly in rom/pod.py:38); HBM-bound streaming kernel. */
+int rt_rank_update(rt_ctx* ctx, const double* Ysrc, int64_t ldys, const double* colscale, const double* X, int64_t ldx,
+                   const double* T, int64_t ldt, int64_t N, int64_t k, int64_t n, double alpha, double* Ydst,
+                   int64_t ldyd);
+
 /* Out-of-place transpose: dst (cols x rows, row-major, ld_dst) = src (rows x cols, row-major, ld_src)^T. */
 int rt_transpose(rt_ctx* ctx, const double* src, int64_t rows, int64_t cols, int64_t ld_src, double* dst,
                  int64_t ld_dst);

@@ -38,6 +38,7 @@ SIGNATURES = {
     "rt_gram_scale": (_int, [_p, _p, _i64, _p, _int, _p]),
     "rt_gemm_tn": (_int, [_p, _p, _i64, _int, _p, _i64, _int, _i64, _i64, _i64, _p, _i64]),
     "rt_gemm_nn": (_int, [_p, _p, _i64, _int, _p, _i64, _i64, _i64, _i64, _p, _i64, _int]),
+    "rt_rank_update": (_int, [_p, _p, _i64, _p, _p, _i64, _p, _i64, _i64, _i64, _i64, C.c_double, _p, _i64]),
     "rt_gemm_nn_axpby": (_int, [_p, _p, _i64, _int, _p, _i64, _i64, _i64, _i64, C.c_double, C.c_double, _p, _i64, _int]),
     "rt_transpose": (_int, [_p, _p, _i64, _i64, _i64, _p, _i64]),
     "rt_deim_greedy": (_int, [_p, _p, _i64, _i64, _i64, _int, _p, _p, _p]),

@@ -119,6 +119,29 @@ def gemm_nn(X: torch.Tensor, T: torch.Tensor, out: torch.Tensor = None, alpha: f
     return Y
 
 
+def rank_update(Ysrc: torch.Tensor, X: torch.Tensor, T: torch.Tensor, alpha: float = -1.0, colscale: torch.Tensor = None,
+                out: torch.Tensor = None) -> torch.Tensor:
+    """``out = Ysrc diag(colscale) + alpha X T`` for a tall row-major Ysrc (N x n), thin X (N x k) and T (k x n);
+    ``out`` may be Ysrc itself.  k <= 64 runs the streaming kernel (rt_rank_update), larger k the GEMM epilogue."""
+    ctx = Context.current()
+    N, n = Ysrc.shape
+    k = X.shape[1]
+    if tuple(T.shape) != (k, n) or X.shape[0] != N:
+        raise RomtimeHipError("rank_update: shapes do not match")
+    row_major = all(t.is_contiguous() or (t.stride(1) == 1 and t.stride(0) >= t.shape[1]) for t in (Ysrc, X))
+    if k > 64 or not row_major or (out is not None and not out.is_contiguous()):
+        base = Ysrc * colscale[None, :] if colscale is not None else Ysrc
+        out = base.clone() if (out is None and base is Ysrc) else (base if out is None else out.copy_(base))
+        return gemm_nn(X, T, out=out, alpha=alpha, beta=1.0)
+    T = T.contiguous()
+    if out is None:
+        out = torch.empty((N, n), dtype=torch.float64, device=Ysrc.device)
+    ctx.check(ctx.lib.rt_rank_update(ctx.handle, _ptr(Ysrc), Ysrc.stride(0), _ptr(colscale) if colscale is not None else None,
+                                     _ptr(X), X.stride(0), _ptr(T), n, N, k, n, float(alpha), _ptr(out), out.stride(0)),
+              "rt_rank_update")
+    return out
+
+
 def deim_greedy(Phi: torch.Tensor, want_margin: bool = True):
     """(idx int64[m], PT_U [m,m], margin [m] or None), all on the device. rt_deim_greedy."""
     ctx = Context.current()

@@ -82,6 +82,9 @@ def _profiling(ctx) -> bool:
     return bool(getattr(ctx, "profiling", False))
 
 
+_THREADPOOLS = None  # threadpoolctl.ThreadpoolController, built once: scanning the loaded libraries takes ~2 ms
+
+
 class _blas_threads:
     """Cap the BLAS/OpenMP pools around the small host-side dense steps.  On a GPU box one process
     owns a 16-core share of a 256-thread socket: an uncapped OpenBLAS spins 64+ threads, exhausts
@@ -91,10 +94,13 @@ class _blas_threads:
         self.n, self.ctx = n, None
 
     def __enter__(self):
+        global _THREADPOOLS
         try:
-            from threadpoolctl import threadpool_limits
+            if _THREADPOOLS is None:
+                from threadpoolctl import ThreadpoolController
 
-            self.ctx = threadpool_limits(limits=self.n)
+                _THREADPOOLS = ThreadpoolController()
+            self.ctx = _THREADPOOLS.limit(limits=self.n)
             self.ctx.__enter__()
         except ImportError:
             self.ctx = None
@@ -227,7 +233,7 @@ class _SmallEig:
         HS = torch.cat([ops.gemm_tn(Z, GZ), ops.gemm_tn(Z, Z)], dim=0).cpu().numpy()
         H, S = 0.5 * (HS[:k] + HS[:k].T), 0.5 * (HS[k:] + HS[k:].T)
         with _blas_threads(1):  # k x k: threads only burn the CPU quota
-            theta, C = small_eigh(H, S)
+            theta, C = small_eigh(H, S, check_finite=False)
         theta, C = theta[::-1], np.ascontiguousarray(C[:, ::-1])
         if np.abs(theta - lam[:k]).max() > 1e-9 * max(lam[0], 1e-300):
             raise _lib.RomtimeHipError("device eigenvectors failed the Rayleigh-Ritz cross-check")
@@ -440,15 +446,19 @@ def _pod_deflated(X, eig0, colnorm, normalize, num, tol, group, want_vt):
         r = truncation_rank(s_full, energy, num=num, tol=tol)
         if r <= got or k == 0 or got >= n or levels >= MAX_LEVELS or tail.size == 0 or tail[0] <= 0.0:
             break
-        # deflate: X <- X - Q (Q^T X), twice (classical Gram-Schmidt needs the second sweep)
-        fresh = Xc is None     # first level: the caller's X must stay intact, later levels update Xc in place
-        if fresh:
-            Xc = X / colnorm[None, :] if normalize else X
+        # deflate: X <- X - Q (Q^T X), twice (classical Gram-Schmidt needs the second sweep).  The first sweep of
+        # the first level reads the caller's X (which must stay intact) and writes the working copy, folding the
+        # column normalisation in; every later sweep updates the working copy in place (rt_rank_update).
         for sweep in range(2):
-            C = _allreduce(ops.gemm_tn(Ql, Xc), group)  # Q^T X sums over the row slabs of all ranks
-            if fresh and not normalize and sweep == 0:
-                Xc = Xc.clone()                         # the caller's X must stay intact
-            ops.gemm_nn(Ql, C, out=Xc, alpha=-1.0, beta=1.0)   # Xc -= Ql C in the GEMM's own epilogue
+            if Xc is None:
+                inv = (1.0 / colnorm) if normalize else None
+                C = _allreduce(ops.gemm_tn(Ql, X), group)   # Q^T X sums over the row slabs of all ranks
+                if inv is not None:
+                    C = C * inv[None, :]
+                Xc = ops.rank_update(X, Ql, C, alpha=-1.0, colscale=inv)
+            else:
+                C = _allreduce(ops.gemm_tn(Ql, Xc), group)
+                ops.rank_update(Xc, Ql, C, alpha=-1.0, out=Xc)
         G = _allreduce(ops.gram(Xc), group)
         eig = _SmallEig(G, group=group)
     Q = torch.cat(Q_acc, dim=1)[:, :r].contiguous() if (r > 0 and Q_acc) else X.new_zeros((X.shape[0], 0))

@@ -342,3 +342,31 @@ def test_pod_work_enqueued_ahead_of_the_eigenvalues(ops, decay, expect_ahead):
     assert np.all(np.abs(first["s"][:k] - so[:k]) <= 2e-13 * so[0] + 8 * np.finfo(float).eps * so[0] ** 2 / so[:k])
     Q = first["Q"].cpu().numpy()
     assert np.abs(np.abs(np.sum(Q * Qo, axis=0)) - 1.0).max() < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,n,k", [(5000, 200, 8), (4099, 131, 1), (3000, 512, 64), (2000, 96, 65), (777, 33, 5)])
+@pytest.mark.parametrize("mode", ["in_place", "out_of_place_scaled", "col_major"])
+def test_rank_update(ops, N, n, k, mode):
+    """Y diag(d) + alpha X T against NumPy: the streaming kernel (k <= 64, row-major) and the GEMM-epilogue route
+    (k > 64 or column-major snapshots) give the same update; Y_src stays intact when out of place."""
+    rng = np.random.RandomState(N + n + k)
+    Y, X, T = rng.standard_normal((N, n)), rng.standard_normal((N, k)), rng.standard_normal((k, n))
+    d = rng.uniform(0.5, 2.0, n)
+    Xd, Td = ops.to_device(X), ops.to_device(T)
+    if mode == "in_place":
+        Yd = ops.to_device(Y)
+        out = ops.rank_update(Yd, Xd, Td, alpha=-1.0, out=Yd)
+        assert out.data_ptr() == Yd.data_ptr()
+        ref = Y - X @ T
+    elif mode == "out_of_place_scaled":
+        Yd = ops.to_device(Y)
+        out = ops.rank_update(Yd, Xd, Td, alpha=-1.0, colscale=ops.to_device(d))
+        np.testing.assert_array_equal(Yd.cpu().numpy(), Y)
+        ref = Y * d[None, :] - X @ T
+    else:
+        Yd = ops.to_device(np.asfortranarray(Y))
+        out = ops.rank_update(Yd, Xd, Td, alpha=0.5)
+        np.testing.assert_array_equal(Yd.cpu().numpy(), Y)
+        ref = Y + 0.5 * X @ T
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=1e-12 * max(1, k))
