@@ -1,4 +1,4 @@
-// Tall-skinny product  Y (N x k) = X (N x n, row-major) T (n x k),  k <= 64: the POD back-projection
+// Tall-skinny product  Y (N x k) = X (N x n, row-major) T (n x k),  k <= 128: the POD back-projection
 // U_r = X W (pod.py:38 folded into the Gram route, SURVEY 8d "POD pass 2") and the lift u_h = V u_N.
 //
 // 8 N (n + k) bytes for 2 N n k flops: at k = 40 (three 16-wide MFMA column tiles) the matrix-core time is
@@ -31,7 +31,7 @@ struct TsParams {
 };
 
 template <int NT>
-__global__ __launch_bounds__(TS_THREADS, 4) void tallskinny_kernel(const TsParams p) {
+__global__ __launch_bounds__(TS_THREADS, NT <= 4 ? 4 : 2) void tallskinny_kernel(const TsParams p) {
   constexpr int KP = 16 * NT;                                 // padded output width
   constexpr int TL = (TS_KS * KP / 2 + TS_THREADS - 1) / TS_THREADS;  // d2 loads of T per thread and stage
   __shared__ __attribute__((aligned(16))) double sA[TS_BM * TS_SA];
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(TS_THREADS, 4) void tallskinny_kernel(const TsParam
 // RT_ERR_UNSUPPORTED: shape outside this kernel's range (the caller uses the generic GEMM).
 int rt_tallskinny(rt_ctx* ctx, const double* X, int64_t ldx, const double* T, int64_t ldt, int64_t N, int64_t n,
                   int64_t k, double* Y, int64_t ldy) {
-  if (k > 64 || n < 2 * TS_KS || N < 64L * ctx->num_cus) return RT_ERR_UNSUPPORTED;
+  if (k > 128 || n < 2 * TS_KS || N < 64L * ctx->num_cus) return RT_ERR_UNSUPPORTED;
   TsParams p{X, T, Y, (long)N, (long)ldx, (long)ldt, (long)ldy, (int)n, (int)k};
   const unsigned grid = (unsigned)((N + TS_BM - 1) / TS_BM);
   const int nt = (int)((k + 15) / 16);
@@ -142,7 +142,11 @@ int rt_tallskinny(rt_ctx* ctx, const double* X, int64_t ldx, const double* T, in
     case 1: hipLaunchKernelGGL(tallskinny_kernel<1>, dim3(grid), dim3(TS_THREADS), 0, ctx->stream, p); break;
     case 2: hipLaunchKernelGGL(tallskinny_kernel<2>, dim3(grid), dim3(TS_THREADS), 0, ctx->stream, p); break;
     case 3: hipLaunchKernelGGL(tallskinny_kernel<3>, dim3(grid), dim3(TS_THREADS), 0, ctx->stream, p); break;
-    default: hipLaunchKernelGGL(tallskinny_kernel<4>, dim3(grid), dim3(TS_THREADS), 0, ctx->stream, p); break;
+    case 4: hipLaunchKernelGGL(tallskinny_kernel<4>, dim3(grid), dim3(TS_THREADS), 0, ctx->stream, p); break;
+    case 5: hipLaunchKernelGGL(tallskinny_kernel<5>, dim3(grid), dim3(TS_THREADS), 0, ctx->stream, p); break;
+    case 6: hipLaunchKernelGGL(tallskinny_kernel<6>, dim3(grid), dim3(TS_THREADS), 0, ctx->stream, p); break;
+    case 7: hipLaunchKernelGGL(tallskinny_kernel<7>, dim3(grid), dim3(TS_THREADS), 0, ctx->stream, p); break;
+    default: hipLaunchKernelGGL(tallskinny_kernel<8>, dim3(grid), dim3(TS_THREADS), 0, ctx->stream, p); break;
   }
   RT_HIP_CHECK(ctx, hipGetLastError());
   if (ctx->profile) {

@@ -422,18 +422,22 @@ def _pod_deflated(X, eig0, colnorm, normalize, num, tol, group, want_vt):
     total = float(np.sum(np.clip(eig0.lam, 0.0, None)))   # == trace(G0): the energy denominator
     Xc, eig = None, eig0
     s_acc, Q_acc, W_acc = [], [], []
+    # with ``num`` alone the basis never has more than num columns: the levels write straight into it
+    cap = int(min(num, n)) if (num and not tol) else None
+    Qbuf = torch.empty((X.shape[0], cap), dtype=torch.float64, device=dev) if cap else None
     levels = 0
     while True:
         levels += 1
         sig = np.sqrt(np.clip(eig.lam, 0.0, None))
-        room = n - sum(len(x) for x in s_acc)
+        have = sum(len(x) for x in s_acc)
+        room = (cap if cap else n) - have
         k = int(min(max(1, np.count_nonzero(sig >= TWO_PASS_RATIO * sig[0])), room)) if sig[0] > 0 else 0
         if k > 0:
             Z = eig.vectors(k)
             src = X if Xc is None else Xc
             scale = ops.to_device(_inv_or_zero(sig[:k]), dev)[None, :]
             Zs = (Z / colnorm[:, None] if (normalize and Xc is None) else Z) * scale
-            Ql = ops.gemm_nn(src, Zs.contiguous())
+            Ql = ops.gemm_nn(src, Zs.contiguous(), out=Qbuf[:, have:have + k] if cap else None)
             s_acc.append(sig[:k])
             Q_acc.append(Ql)
             if want_vt:
@@ -461,7 +465,10 @@ def _pod_deflated(X, eig0, colnorm, normalize, num, tol, group, want_vt):
                 ops.rank_update(Xc, Ql, C, alpha=-1.0, out=Xc)
         G = _allreduce(ops.gram(Xc), group)
         eig = _SmallEig(G, group=group)
-    Q = torch.cat(Q_acc, dim=1)[:, :r].contiguous() if (r > 0 and Q_acc) else X.new_zeros((X.shape[0], 0))
+    if cap:
+        Q = Qbuf if r == cap else Qbuf[:, :r].contiguous()
+    else:
+        Q = torch.cat(Q_acc, dim=1)[:, :r].contiguous() if (r > 0 and Q_acc) else X.new_zeros((X.shape[0], 0))
     VT = np.ascontiguousarray(np.hstack(W_acc)[:, :r].T) if (want_vt and W_acc) else (np.zeros((0, n)) if want_vt else None)
     return Q, s_full, energy, r, VT, levels
 

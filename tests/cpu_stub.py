@@ -54,6 +54,15 @@ def gemm_nn(X, T, out=None, alpha=1.0, beta=0.0):
     return out
 
 
+def rank_update(Ysrc, X, T, alpha=-1.0, colscale=None, out=None):
+    base = Ysrc * colscale[None, :] if colscale is not None else Ysrc
+    res = base + alpha * (X @ T)
+    if out is not None:
+        out.copy_(res)
+        return out
+    return res
+
+
 def deim_greedy(Phi, want_margin=True):
     dofs, PT_U, margin = oracle.deim_greedy(_np(Phi))
     return torch.from_numpy(dofs), torch.from_numpy(np.ascontiguousarray(PT_U)), torch.from_numpy(margin)
@@ -92,6 +101,6 @@ def dense_solve(K, b):
 def install(monkeypatch):
     from romtime_amd import ops
 
-    for name in ("to_device", "to_device_index", "gram", "gram_scale", "gemm_tn", "gemm_nn", "deim_greedy",
+    for name in ("to_device", "to_device_index", "gram", "gram_scale", "gemm_tn", "gemm_nn", "rank_update", "deim_greedy",
                  "csr_spmm", "project_csr", "project_csr_batched", "dense_solve"):
         monkeypatch.setattr(ops, name, globals()[name])

@@ -27,7 +27,7 @@ def _worker(rank, world, port, X, kwargs, ret):
         from romtime_amd import ops, pod
         from tests import cpu_stub
 
-        for name in ("to_device", "to_device_index", "gram", "gram_scale", "gemm_tn", "gemm_nn"):
+        for name in ("to_device", "to_device_index", "gram", "gram_scale", "gemm_tn", "gemm_nn", "rank_update"):
             setattr(ops, name, getattr(cpu_stub, name))
         rows = np.array_split(np.arange(X.shape[0]), world)[rank]
         out = pod.pod_device(torch.from_numpy(X[rows]), group=dist.group.WORLD, **kwargs)
