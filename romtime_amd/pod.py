@@ -450,9 +450,12 @@ def _pod_deflated(X, eig0, colnorm, normalize, num, tol, group, want_vt):
         r = truncation_rank(s_full, energy, num=num, tol=tol)
         if r <= got or k == 0 or got >= n or levels >= MAX_LEVELS or tail.size == 0 or tail[0] <= 0.0:
             break
-        # deflate: X <- X - Q (Q^T X), twice (classical Gram-Schmidt needs the second sweep).  The first sweep of
-        # the first level reads the caller's X (which must stay intact) and writes the working copy, folding the
-        # column normalisation in; every later sweep updates the working copy in place (rt_rank_update).
+        # deflate: X <- X - Q (Q^T X), twice (classical Gram-Schmidt needs the second sweep; taking its
+        # coefficients from the k x k matrix Q^T Q instead, C = (2I - Q^T Q) Q^T X, saves a pass over the snapshots
+        # but leaves the rounding of the first update along Q in place: deep modes 2.5x less accurate).
+        # The first sweep of the first level reads the caller's X (which must stay intact) and writes the working
+        # copy, folding the column normalisation in; every later sweep updates the working copy in place
+        # (rt_rank_update).
         for sweep in range(2):
             if Xc is None:
                 inv = (1.0 / colnorm) if normalize else None

@@ -50,7 +50,7 @@ def gemm_tn(A, B):
 def gemm_nn(X, T, out=None, alpha=1.0, beta=0.0):
     if out is None:
         return alpha * (X @ T) if alpha != 1.0 else X @ T
-    out.copy_(beta * out + alpha * (X @ T))
+    out.copy_(alpha * (X @ T) if beta == 0.0 else beta * out + alpha * (X @ T))  # beta = 0: `out` may be uninitialised
     return out
 
 
