@@ -38,15 +38,13 @@ struct GramParams {
   unsigned char slot_tm[MAX_SLOTS], slot_tn[MAX_SLOTS], slot_q[MAX_SLOTS], slot_S[MAX_SLOTS];
 };
 
-// MFMA-tile sets of a diagonal 128x128 tile (8x8 grid of 16x16 tiles, only i <= j), 9 per wave.
-// Wave 0: upper triangle of the top-left quadrant minus (3,3); wave 3: that of the bottom-right
-// quadrant minus (4,4); waves 1/2: two rows each of the top-right quadrant plus (3,3) / (4,4).
+// MFMA-tile sets of a diagonal 128x128 tile (8x8 grid of 16x16 tiles, only i <= j: 36 tiles): waves 0-3 take five
+// consecutive tiles of the row-wise list each, waves 4-7 four.  Waves w and w + 4 of a workgroup share a SIMD, so
+// every SIMD issues 9 MFMAs per k-step (5,5,5,5,5,5,4,2 put 10 on two of them: 10 % of the kernel).
 // The operands of each MFMA are read from LDS at run-time offsets (no register-array indexing),
-// so all four waves run the same instruction stream.
-__device__ const unsigned char kDiagTi[8][5] = {{0, 0, 0, 0, 1}, {1, 1, 2, 2, 3}, {0, 0, 0, 0, 1}, {1, 1, 1, 2, 2},
-                                                {2, 2, 3, 3, 3}, {3, 4, 4, 4, 4}, {5, 5, 5, 6, 255}, {6, 7, 255, 255, 255}};
-__device__ const unsigned char kDiagTj[8][5] = {{0, 1, 2, 3, 1}, {2, 3, 2, 3, 3}, {4, 5, 6, 7, 4}, {5, 6, 7, 4, 5},
-                                                {6, 7, 4, 5, 6}, {7, 4, 5, 6, 7}, {5, 6, 7, 6, 0}, {7, 7, 0, 0, 0}};
+// so all waves run the same instruction stream.
+__device__ const unsigned char kDiagTi[8][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 1, 1}, {1, 1, 1, 1, 1}, {2, 2, 2, 2, 2}, {2, 3, 3, 3, 255}, {3, 3, 4, 4, 255}, {4, 4, 5, 5, 255}, {5, 6, 6, 7, 255}};
+__device__ const unsigned char kDiagTj[8][5] = {{0, 1, 2, 3, 4}, {5, 6, 7, 1, 2}, {3, 4, 5, 6, 7}, {2, 3, 4, 5, 6}, {7, 3, 4, 5, 0}, {6, 7, 4, 5, 0}, {6, 7, 5, 6, 0}, {7, 6, 7, 7, 0}};
 
 template <bool KC, bool DIAG>
 __global__ __launch_bounds__(GT, 4) void gram128_kernel(const GramParams p) {
