@@ -111,7 +111,7 @@ __device__ __forceinline__ double block_sum(double x, double* s_red) {
 // workgroup applies the update to its copy and derives the next reflector redundantly (and, the
 // arithmetic being identical, bit-identically).  All O(n) vector work of a step (reflector, p.v, w, the
 // look-ahead row) is done by wave 0 alone in registers with DPP reductions - NM / 64 elements per lane -
-// so a step costs four workgroup barriers; the other 15 waves only do the O(n^2/P) mat-vec and update.
+// so a step costs two or three workgroup barriers; the other 15 waves only do the O(n^2/P) mat-vec and update.
 template <int NM>
 __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
@@ -125,7 +125,6 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
   double* sl = sw + n;            // current row k (entries j >= k), maintained by wave 0
   __shared__ int s_abort;
   if (threadIdx.x == 0) s_abort = 0;
-  __shared__ double s_tau;
   constexpr int PER = NM / 64;
 
   for (int q = tid; q < RB * n; q += TT) {
@@ -167,49 +166,80 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
   __syncthreads();
   const bool one_xcd = s_one != 0;
 
-  double v[PER];  // wave 0: the reflector of the current step, element j = k + 1 + lane + 64 q
-  for (int k = 0; k + 2 < n; ++k) {
-    double* sv = svb + (size_t)(k & 1) * n;
-    if (wid == 0) {
-      // reflector of row k (dlarfg): identical data and arithmetic in every workgroup
-      double part = 0.0;
+  __shared__ double s_tauv[2];  // tau of step k in s_tauv[k & 1]
+  // n > 512 (128 workgroups, few rows each): the next step's reflector is formed by wave 0 in the same section as w
+  // and the updated row, straight from registers - two workgroup barriers per column, 10 % faster.  n <= 512: the
+  // reflector is formed after the rank-2 update has been released (three barriers); there the merged form measured
+  // 5 % slower.
+  constexpr bool MERGED = NM > 512;
+  // Reflector (dlarfg) of step kk from the registers of wave 0: x[q] = element j0 + lane + 64 q of row kk, the
+  // reflector starts `off` elements in (alpha = that element, v there = 1).  Identical data and arithmetic in every
+  // workgroup.  Writes v to the step's LDS buffer, tau to s_tauv, and (owner only) V, tau, d, e to memory.
+  auto reflector = [&](const double (&x)[PER], int kk, int j0, int off, double diag) {
+    double part = 0.0;
 #pragma unroll
-      for (int q = 0; q < PER; ++q) {
-        const int j = k + 1 + lane + 64 * q;
-        v[q] = (j < n) ? sl[j] : 0.0;
-        if (!(lane == 0 && q == 0)) part = fma(v[q], v[q], part);
-      }
-      part = rtw::wave_sum(part);
-      const double alpha = rtw::first_lane(v[0]);
-      double tau, beta, scale;
-      if (part == 0.0) {
-        tau = 0.0; beta = alpha; scale = 0.0;
-      } else {
-        beta = -copysign(sqrt(alpha * alpha + part), alpha);
-        tau = (beta - alpha) / beta;
-        scale = 1.0 / (alpha - beta);
-      }
-      const bool owner = (wg == k % TW);
+    for (int q = 0; q < PER; ++q)
+      if (q > 0 || lane > off) part = fma(x[q], x[q], part);  // x is 0 beyond the row's end
+    part = rtw::wave_sum(part);
+    const double alpha = rtw::read_lane(x[0], off);
+    double tau, beta, scale;
+    if (part == 0.0) {
+      tau = 0.0; beta = alpha; scale = 0.0;
+    } else {
+      beta = -copysign(sqrt(alpha * alpha + part), alpha);
+      tau = (beta - alpha) / beta;
+      scale = 1.0 / (alpha - beta);
+    }
+    const bool owner = (wg == kk % TW);
+    double* svk = svb + (size_t)(kk & 1) * n;
 #pragma unroll
-      for (int q = 0; q < PER; ++q) {
-        const int j = k + 1 + lane + 64 * q;
-        v[q] = (lane == 0 && q == 0) ? 1.0 : v[q] * scale;
-        if (j < n) {
-          sv[j] = v[q];
-          if (owner) p.V[(size_t)k * n + j] = v[q];
-        }
-      }
-      if (lane == 0) {
-        s_tau = tau;
-        if (owner) {
-          p.tau[k] = tau;
-          p.d[k] = sl[k];
-          p.e[k] = beta;
-        }
+    for (int q = 0; q < PER; ++q) {
+      const int j = j0 + lane + 64 * q;
+      const double vq = (q == 0 && lane == off) ? 1.0 : x[q] * scale;
+      if (j < n && (q > 0 || lane >= off)) {
+        svk[j] = vq;
+        if (owner) p.V[(size_t)kk * n + j] = vq;
       }
     }
-    __syncthreads();  // B1: sv, s_tau
-    const double tau = s_tau;
+    if (lane == 0) {
+      s_tauv[kk & 1] = tau;
+      if (owner) {
+        p.tau[kk] = tau;
+        p.d[kk] = diag;
+        p.e[kk] = beta;
+      }
+    }
+  };
+
+  // A step is: mat-vec (all waves) -> hand-off -> wave 0 alone: w, the updated next row AND from it the next
+  // step's reflector, all in registers -> rank-2 update (all waves)  [MERGED; otherwise the reflector follows the update].
+  if (wid == 0 && n > 2) {
+    double x[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+      const int j = 1 + lane + 64 * q;
+      x[q] = (j < n) ? sl[j] : 0.0;
+    }
+    reflector(x, 0, 1, 0, sl[0]);
+  }
+  __syncthreads();
+  for (int k = 0; k + 2 < n; ++k) {
+    const double* sv = svb + (size_t)(k & 1) * n;
+    if constexpr (!MERGED) {
+      if (k > 0) {
+        if (wid == 0) {  // reflector of row k from the row as wave 0 left it in LDS
+          double x[PER];
+#pragma unroll
+          for (int q = 0; q < PER; ++q) {
+            const int j = k + 1 + lane + 64 * q;
+            x[q] = (j < n) ? sl[j] : 0.0;
+          }
+          reflector(x, k, k + 1, 0, sl[k]);
+        }
+        __syncthreads();  // B1
+      }
+    }
+    const double tau = s_tauv[k & 1];
     // ---- p = tau * A v on the local rows i > k; the wave that holds row k+1 adds that row (pre-update) ----
     double* Pk = p.P + (size_t)(k & 1) * n;
     double* Lk = p.P + (size_t)(2 + (k & 1)) * n;
@@ -233,44 +263,51 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
     // buffers alternate, so a fast workgroup never overwrites what a slow one still reads.  Wave 0 arrives, waits
     // and goes straight on to the payload; the other waves meet it again at B5.
     ++hop;
-    if (wid == 0 && lane == 0) st_slot(&p.flags[SLOT0 + wg], hop, one_xcd);
-    if (wid == 0 && !poll_slots(&p.flags[SLOT0], TW, hop, &p.flags[3])) {
-      if (lane == 0) s_abort = 1;
-    } else if (wid == 0) {
-      // wave 0 takes p and the next row straight into registers
-      double pv[PER], lv[PER];
+    if (wid == 0) {
+      if (lane == 0) st_slot(&p.flags[SLOT0 + wg], hop, one_xcd);
+      double v[PER];  // this step's reflector, element j = k + 1 + lane + 64 q (LDS read in flight during the poll)
 #pragma unroll
       for (int q = 0; q < PER; ++q) {
         const int j = k + 1 + lane + 64 * q;
-        lv[q] = (j < n) ? ld_wt(&Lk[j]) : 0.0;
-        pv[q] = (j < n && tau != 0.0) ? ld_wt(&Pk[j]) : 0.0;
+        v[q] = (j < n) ? sv[j] : 0.0;
       }
-      if (tau != 0.0) {
-        double dot = 0.0;
-#pragma unroll
-        for (int q = 0; q < PER; ++q) dot = fma(pv[q], v[q], dot);
-        dot = rtw::wave_sum(dot);
-        const double alpha2 = -0.5 * tau * dot;
-#pragma unroll
-        for (int q = 0; q < PER; ++q) pv[q] = fma(alpha2, v[q], pv[q]);  // pv now holds w
-        const double w1 = rtw::first_lane(pv[0]);                        // w_{k+1}; v_{k+1} = 1
+      if (!poll_slots(&p.flags[SLOT0], TW, hop, &p.flags[3])) {
+        if (lane == 0) s_abort = 1;
+      } else {
+        // wave 0 takes p and the next row straight into registers
+        double pv[PER], x[PER];
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
           const int j = k + 1 + lane + 64 * q;
-          if (j < n) {
-            sw[j] = pv[q];
-            sl[j] = lv[q] - (pv[q] + w1 * v[q]);  // row k+1 after the rank-2 update
+          x[q] = (j < n) ? ld_wt(&Lk[j]) : 0.0;
+          pv[q] = (j < n && tau != 0.0) ? ld_wt(&Pk[j]) : 0.0;
+        }
+        if (tau != 0.0) {
+          double dot = 0.0;
+#pragma unroll
+          for (int q = 0; q < PER; ++q) dot = fma(pv[q], v[q], dot);
+          dot = rtw::wave_sum(dot);
+          const double alpha2 = -0.5 * tau * dot;
+#pragma unroll
+          for (int q = 0; q < PER; ++q) pv[q] = fma(alpha2, v[q], pv[q]);  // pv now holds w
+          const double w1 = rtw::first_lane(pv[0]);                        // w_{k+1}; v_{k+1} = 1
+#pragma unroll
+          for (int q = 0; q < PER; ++q) {
+            const int j = k + 1 + lane + 64 * q;
+            x[q] = (j < n) ? x[q] - (pv[q] + w1 * v[q]) : 0.0;  // row k+1 after the rank-2 update
+            if (j < n) sw[j] = pv[q];
           }
         }
-      } else {
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
           const int j = k + 1 + lane + 64 * q;
-          if (j < n) sl[j] = lv[q];
+          if (j < n) sl[j] = x[q];  // read again only for the trailing 2 x 2
         }
+        if constexpr (MERGED)
+          if (k + 3 < n) reflector(x, k + 1, k + 1, 1, rtw::first_lane(x[0]));
       }
     }
-    __syncthreads();  // B5: sw, sl
+    __syncthreads();  // B5: sw, the next step's v and tau
     if (s_abort) return;
     if (tau == 0.0) continue;
     // ---- A <- A - v w^T - w v^T on the local rows i > k (each wave touches only the rows it also reads) ----
