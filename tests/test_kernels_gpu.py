@@ -370,3 +370,31 @@ def test_rank_update(ops, N, n, k, mode):
         np.testing.assert_array_equal(Yd.cpu().numpy(), Y)
         ref = Y + 0.5 * X @ T
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=0, atol=1e-12 * max(1, k))
+
+
+@pytest.mark.gpu
+def test_eigensolver_hand_off_forms_agree_bitwise(ops):
+    """rt_ctx_set_option("eig_one_xcd"): the one-XCD hand-off (plain stores through one L2) and the write-through
+    form move the same numbers, so eigenvalues and eigenvectors are bit-identical; unknown options are refused."""
+    from romtime_amd._lib import Context, RomtimeHipError
+
+    ctx = Context.current()
+    rng = np.random.RandomState(3)
+    n = 300
+    A = rng.standard_normal((n, n))
+    G = ops.to_device(A @ A.T)
+    try:
+        ctx.set_option("eig_one_xcd", 1)
+        lam1, st1 = ops.sym_eig_values(G)
+        W1 = ops.sym_eig_vectors(lam1, 12)
+        ctx.set_option("eig_one_xcd", 0)
+        lam0, st0 = ops.sym_eig_values(G)
+        W0 = ops.sym_eig_vectors(lam0, 12)
+    finally:
+        ctx.set_option("eig_one_xcd", 1)
+    assert int(st1) == 0 and int(st0) == 0
+    assert torch.equal(lam1, lam0) and torch.equal(W1, W0)
+    ref = np.linalg.eigvalsh(A @ A.T)[::-1]
+    np.testing.assert_allclose(lam1.cpu().numpy(), ref, rtol=0, atol=1e-12 * ref[0])
+    with pytest.raises(RomtimeHipError):
+        ctx.set_option("no_such_option", 1)
