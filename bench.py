@@ -87,8 +87,8 @@ def cpu_baseline(n, r, sample_rows):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--rows", type=int, default=N_H)
     ap.add_argument("--cols", type=int, default=N_S)
     ap.add_argument("--modes", type=int, default=R_MODES)
