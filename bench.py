@@ -80,7 +80,7 @@ def cpu_baseline(n, r, sample_rows):
         Q, s, energy = oracle.orth(X, num=r, normalize=True)
         dt = time.perf_counter() - t0
     return dict(value=sample_rows * n / dt, unit="snapshot-DoF/s", cores=cores, kind="port",
-                sample=f"oracle.orth (scipy dgesvd) on the first {sample_rows} x {n} rows of the workload, "
+                sample=f"oracle.orth (scipy dgesvd) on {'the whole' if sample_rows >= N_H else 'the first'} {sample_rows} x {n} rows of the workload, "
                        f"{dt:.2f} s, numpy {np.__version__}")
 
 
@@ -92,7 +92,7 @@ def main():
     ap.add_argument("--rows", type=int, default=N_H)
     ap.add_argument("--cols", type=int, default=N_S)
     ap.add_argument("--modes", type=int, default=R_MODES)
-    ap.add_argument("--cpu-sample-rows", type=int, default=100_000)
+    ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
