@@ -53,7 +53,10 @@ int rt_last_launch_info(rt_ctx* ctx, int64_t* info3);
 int rt_ctx_set_profile(rt_ctx* ctx, int on);
 /* Named switches.  "eig_one_xcd" (default 1): the small eigensolver may place its cooperating workgroups on one
  * XCD and hand off through that XCD's L2 (placement is verified on the device); it needs every CU of that XCD,
- * so processes that share a GPU turn it off (a hand-off timeout of rt_sym_eig_values is the symptom). */
+ * so processes that share a GPU turn it off (a hand-off timeout of rt_sym_eig_values is the symptom).
+ * "sweep_graph" (default 0): rt_hrom_bdf_sweep captures one time step as a hipGraph (its kernels read the step from a
+ * device counter) and replays it for steps 1 .. nt-1 instead of launching four kernels per step; for hosts that
+ * cannot keep ahead of the device.  The call then returns only when the sweep has finished. */
 int rt_ctx_set_option(rt_ctx* ctx, const char* name, int value);
 int rt_last_gemm_ms(rt_ctx* ctx, double* ms);
 /* The same for the most recent launch of the snapshot Gram kernel (rt_gram, n >= 97, long X): its own event pair,

@@ -215,6 +215,10 @@ int rt_ctx_set_option(rt_ctx* ctx, const char* name, int value) {
     ctx->eig_one_xcd = value != 0;
     return RT_OK;
   }
+  if (key == "sweep_graph") {
+    ctx->sweep_graph = value != 0;
+    return RT_OK;
+  }
   ctx->err = "rt_ctx_set_option: unknown option " + key;
   return RT_ERR_ARG;
 }

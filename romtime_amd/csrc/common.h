@@ -21,6 +21,7 @@ struct rt_ctx {
   bool ev_valid = false;
   hipEvent_t gev0 = nullptr, gev1 = nullptr;  // the Gram kernel's own pair (rt_last_gram_ms): survives later GEMMs
   bool gev_valid = false;
+  bool sweep_graph = false;         // rt_hrom_bdf_sweep replays steps 1.. as a hipGraph (rt_ctx_set_option)
   bool eig_one_xcd = true;          // allow the one-XCD form of the eigensolver's hand-off (rt_ctx_set_option)
   // state handed from rt_sym_eig_values to rt_sym_eig_vectors (pointers into the composite arena)
   struct {
@@ -78,6 +79,8 @@ struct rt_newton_rhs {  // b = M_N (c0 u^n + c1 u^{n-1}) + dt Zf^T F_rhs, per sy
   const double* Ff;    // B x mf
   const double* Zf;    // mf x r
   int mf;
+  const long* ctr = nullptr;  // device step counter: Ff is the table base and the step's rows start at *ctr * ff_stride
+  long ff_stride = 0;         // (graph replay of a sweep: the launch parameters cannot carry the step)
 };
 int rt_newton_solve_batched(rt_ctx* ctx, const double* K, double* Xinv, double* rhs, int64_t r, int64_t B,
                             int have_prev, int* info, const rt_newton_rhs* recipe = nullptr);

@@ -189,11 +189,12 @@ __global__ __launch_bounds__(NS_THREADS) void newton_solve_kernel(const double* 
     if (tid < r) s_vec[1][tid] = rq.c0 * rq.un[(size_t)blockIdx.x * r + tid] + rq.c1 * rq.unm1[(size_t)blockIdx.x * r + tid];
     __syncthreads();
     const double* Mb = rq.MN + (size_t)blockIdx.x * r * r;
+    const double* Ff = rq.ctr ? rq.Ff + *rq.ctr * rq.ff_stride : rq.Ff;
     for (int i = wid; i < r; i += NS_THREADS / 64) {
       double acc = 0.0;
       for (int j = lane; j < r; j += 64) acc = fma(Mb[(size_t)i * r + j], s_vec[1][j], acc);
       double f = 0.0;
-      for (int e = lane; e < rq.mf; e += 64) f = fma(rq.Ff[(size_t)blockIdx.x * rq.mf + e], rq.Zf[(size_t)e * r + i], f);
+      for (int e = lane; e < rq.mf; e += 64) f = fma(Ff[(size_t)blockIdx.x * rq.mf + e], rq.Zf[(size_t)e * r + i], f);
       const double v = rtw::wave_sum(fma(rq.dt, f, acc));
       if (lane == 0) {
         s_vec[0][i] = v;

@@ -75,12 +75,25 @@ __global__ void sweep_store_kernel(const double* __restrict__ x, double* __restr
 // next one from the updated state: one launch between two steps instead of two.
 __global__ void hsweep_advance_kernel(const double* __restrict__ x, double* __restrict__ un,
                                       double* __restrict__ unm1, double* __restrict__ out, long step_done, long nt,
-                                      int keep_prev, int do_store, int do_coef, const double* __restrict__ Fm,
-                                      const double* __restrict__ Fl, const double* __restrict__ W,
-                                      const double* __restrict__ Cn, const double* __restrict__ Sn, int extrapolate,
-                                      int mm, int ml, int mn, int r, double bdf, double dt, double* __restrict__ G) {
+                                      int keep_prev, int do_store, int do_coef, const double* Fm,
+                                      const double* Fl, const double* __restrict__ W,
+                                      const double* Cn, const double* Sn, int extrapolate,
+                                      int mm, int ml, int mn, int r, double bdf, double dt, double* __restrict__ G,
+                                      const long* __restrict__ ctr) {
   extern __shared__ double su[];  // u* of the coming step
   const int b = blockIdx.x, t = threadIdx.x, M = mm + ml + mn;
+  if (ctr) {
+    // graph replay: the step comes from the device counter; Fm / Fl / Cn / Sn are the table bases, bdf is that of
+    // every step after the first
+    step_done = *ctr;
+    const long next = step_done + 1;
+    do_coef = next < nt;
+    const long s2 = do_coef ? next : 0;
+    Fm += s2 * gridDim.x * mm;
+    if (Fl) Fl += s2 * gridDim.x * ml;
+    if (Cn) Cn += s2 * gridDim.x * mn;
+    if (Sn) Sn += s2 * gridDim.x;
+  }
   for (int j = t; j < r; j += blockDim.x) {
     double u = un[(long)b * r + j], up = unm1[(long)b * r + j];
     if (do_store) {
@@ -115,6 +128,8 @@ __global__ void hsweep_advance_kernel(const double* __restrict__ x, double* __re
     G[(long)(gridDim.x + b) * M + e] = (e < mm) ? Fm[(long)b * mm + e] : 0.0;
   }
 }
+
+__global__ void hsweep_count_kernel(long* ctr) { *ctr += 1; }
 
 // rhs[b] = M_N[b] (c0 u_n[b] + c1 u_nm1[b]) + dt Zf^T F_rhs[b]
 __global__ void hsweep_rhs_kernel(const double* __restrict__ MN, const double* __restrict__ un,
@@ -247,7 +262,7 @@ extern "C" int rt_hrom_bdf_sweep(rt_ctx* ctx, const rt_hsweep_desc* d, double* u
   auto take = [&off](size_t bytes) { size_t o = off; off += (bytes + 255) / 256 * 256; return o; };
   const size_t oG = take(sizeof(double) * 2 * B * M), oKN = take(sizeof(double) * 2 * B * rr),
                oRhs = take(sizeof(double) * B * r), oUn = take(sizeof(double) * B * r), oUm = take(sizeof(double) * B * r),
-               oXi = take(sizeof(double) * B * rr), oInfo = take(sizeof(int) * B);
+               oXi = take(sizeof(double) * B * rr), oInfo = take(sizeof(int) * B), oCtr = take(sizeof(long));
   void* base = nullptr;
   int rc = rt_scratch2(ctx, off, &base);
   if (rc != RT_OK) return rc;
@@ -260,6 +275,7 @@ extern "C" int rt_hrom_bdf_sweep(rt_ctx* ctx, const rt_hsweep_desc* d, double* u
   double* unm1 = reinterpret_cast<double*>(b8 + oUm);
   double* Xinv = reinterpret_cast<double*>(b8 + oXi);
   int* info = reinterpret_cast<int*>(b8 + oInfo);
+  long* ctr = reinterpret_cast<long*>(b8 + oCtr);
   RT_HIP_CHECK(ctx, hipMemsetAsync(un, 0, sizeof(double) * B * r, st));
   RT_HIP_CHECK(ctx, hipMemsetAsync(unm1, 0, sizeof(double) * B * r, st));
 
@@ -270,12 +286,63 @@ extern "C" int rt_hrom_bdf_sweep(rt_ctx* ctx, const rt_hsweep_desc* d, double* u
                        next - 1, nt, d->bdf2 ? 1 : 0, do_store, has_next ? 1 : 0, d->F_mass + s2 * B * mm,
                        ml ? d->F_lin + s2 * B * ml : nullptr, d->W, d->C_nl ? d->C_nl + s2 * B * mn : nullptr,
                        d->S_nl ? d->S_nl + s2 * B : nullptr, d->bdf2 ? 1 : 0, (int)mm, (int)ml, (int)mn, (int)r,
-                       (d->bdf2 && next > 0) ? 1.5 : 1.0, d->dt, G);
+                       (d->bdf2 && next > 0) ? 1.5 : 1.0, d->dt, G, (const long*)nullptr);
   };
   advance(0, 0);
   RT_HIP_CHECK(ctx, hipGetLastError());
   const double c0 = d->bdf2 ? 2.0 : 1.0, c1 = d->bdf2 ? -0.5 : 0.0;
+  // Steps 1 .. nt-1 are the same four launches with only table offsets moving.  With rt_ctx_set_option(ctx,
+  // "sweep_graph", 1) they are captured ONCE as a hipGraph whose kernels take the step from a device counter, and
+  // replayed; step 0 runs eagerly (first BDF step, inverse tracking starts, scratch arenas get their sizes).  It is
+  // an option, not the default: on the pool's boxes the host stays ahead of the device with plain launches (92 us
+  // per step, 85 us of them kernels) and the replay is slower (97 us: the graph's own inter-node gaps and the
+  // counter kernel); it pays where the host is what limits the rate (110 us per step was measured on one box).
+  // Not with r > 80 (no inverse tracking) or in profile mode (event pairs inside the GEMM).
+  const bool use_graph = ctx->sweep_graph && nt > 2 && r <= 80 && !ctx->profile;
   for (long step = 0; step < nt; ++step) {
+    if (use_graph && step == 1) {
+      const long one = 1;
+      RT_HIP_CHECK(ctx, hipMemcpyAsync(ctr, &one, sizeof(long), hipMemcpyHostToDevice, st));
+      RT_HIP_CHECK(ctx, hipStreamSynchronize(st));  // `one` is on this stack frame
+      hipGraph_t graph = nullptr;
+      hipGraphExec_t exec = nullptr;
+      // the caller's stream may be the legacy default stream, which cannot capture: the graph is captured and
+      // replayed on a stream of its own (everything before it has completed - the synchronisation above - and the
+      // sweep returns only when the replay has)
+      hipStream_t gs = nullptr;
+      RT_HIP_CHECK(ctx, hipStreamCreateWithFlags(&gs, hipStreamNonBlocking));
+      struct Restore {
+        rt_ctx* c; hipStream_t keep, mine;
+        ~Restore() { c->stream = keep; (void)hipStreamDestroy(mine); }
+      } restore{ctx, st, gs};
+      ctx->stream = gs;
+      st = gs;
+      RT_HIP_CHECK(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+      rc = rt_gemm_strided(ctx, G, 1, M, d->Z, rr, 1, M, 2 * B, rr, KN, rr, 1, false, false);
+      rt_newton_rhs rq{MN, un, unm1, c0, c1, d->dt, mf ? d->F_rhs : nullptr, d->Zf, (int)mf, ctr, B * mf};
+      if (rc == RT_OK) rc = rt_newton_solve_batched(ctx, KN, Xinv, rhs, r, B, 1, info, &rq);
+      if (rc == RT_OK) rc = rt_dense_solve_batched_if(ctx, KN, rhs, r, B, info, info);
+      hipLaunchKernelGGL(hsweep_advance_kernel, dim3((unsigned)B), dim3(256), sizeof(double) * r, st, rhs, un, unm1, uN_out,
+                         0L, nt, d->bdf2 ? 1 : 0, 1, 1, d->F_mass, ml ? d->F_lin : nullptr, d->W, d->C_nl, d->S_nl,
+                         d->bdf2 ? 1 : 0, (int)mm, (int)ml, (int)mn, (int)r, d->bdf2 ? 1.5 : 1.0, d->dt, G,
+                         (const long*)ctr);
+      hipLaunchKernelGGL(hsweep_count_kernel, dim3(1), dim3(1), 0, st, ctr);
+      const hipError_t cap = hipStreamEndCapture(st, &graph);
+      if (rc != RT_OK || cap != hipSuccess || graph == nullptr) {
+        if (graph) (void)hipGraphDestroy(graph);
+        ctx->err = "rt_hrom_bdf_sweep: capturing the step graph failed";
+        return rc != RT_OK ? rc : RT_ERR_HIP;
+      }
+      RT_HIP_CHECK(ctx, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      hipError_t le = hipSuccess;
+      for (long s2 = 1; s2 < nt && le == hipSuccess; ++s2) le = hipGraphLaunch(exec, st);
+      const hipError_t se = hipStreamSynchronize(st);  // the executable graph owns the launch arguments: keep it until done
+      if (le == hipSuccess) le = se;
+      (void)hipGraphExecDestroy(exec);
+      (void)hipGraphDestroy(graph);
+      RT_HIP_CHECK(ctx, le);
+      break;
+    }
     // [K_N; M_N][b][ij] = sum_e G[b][e] Z[e][ij]  (2 B rows)
     rc = rt_gemm_strided(ctx, G, 1, M, d->Z, rr, 1, M, 2 * B, rr, KN, rr, 1, false, false);
     if (rc != RT_OK) return rc;

@@ -287,6 +287,15 @@ def test_hyper_reduced_sweep_synthetic_and_singular_system(ops):
         for b in range(n_mu):
             ref = oracle.hrom_solve(mass, lin, nl, rhs, b, r, nt, dt, bdf2)
             assert np.linalg.norm(uN[b].T - ref) <= 1e-10 * np.linalg.norm(ref), (bdf2, b)
+        # the same sweep with steps 1 .. nt-1 replayed as a hipGraph (kernels read the step from a device counter):
+        # identical launches, identical numbers
+        from romtime_amd._lib import Context
+        Context.current().set_option("sweep_graph", 1)
+        try:
+            uG = hrom_bdf_sweep(mass, lin, nl, rhs, dt, bdf2=bdf2).cpu().numpy()
+        finally:
+            Context.current().set_option("sweep_graph", 0)
+        np.testing.assert_array_equal(uG, uN)
         # parameter point 1: every operator coefficient zero -> K_N = 0
         dead = lambda term: dict(term, F=np.where(np.arange(n_mu)[None, :, None] == 1, 0.0, term["F"]))
         nl_dead = dict(nl, C=np.where(np.arange(n_mu)[None, :, None] == 1, 0.0, nl["C"]),
