@@ -367,15 +367,41 @@ int rt_project_stage_table(rt_ctx* ctx, const int64_t* indptr, const int64_t* in
 }
 
 template <int TR>
-static int launch_fused(rt_ctx* ctx, const ProjParams& p, unsigned grid) {
-  const size_t lds = sizeof(double) * (size_t)(WROWS + PK) * stride_of(TR) + sizeof(Entry) * EMAX;
-  static bool attr_set = false;
-  if (!attr_set) {
+static constexpr size_t fused_lds() {
+  return sizeof(double) * (size_t)(WROWS + PK) * stride_of(TR) + sizeof(Entry) * EMAX;
+}
+
+// workgroups of project_fused_kernel<TR> that fit one CU (LDS and registers), asked of the runtime once per TR
+template <int TR>
+static int fused_blocks_per_cu(rt_ctx* ctx, int* out) {
+  static int cached = 0;
+  if (cached == 0) {
     RT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&project_fused_kernel<TR>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
-    attr_set = true;
+    int nb = 0;
+    RT_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, project_fused_kernel<TR>, PT, fused_lds<TR>()));
+    cached = nb > 0 ? nb : 1;
   }
-  hipLaunchKernelGGL((project_fused_kernel<TR>), dim3(grid), dim3(PT), lds, ctx->stream, p);
+  *out = cached;
+  return RT_OK;
+}
+
+static int fused_blocks_per_cu(rt_ctx* ctx, int tr, int* out) {
+  switch (tr) {
+    case 1: return fused_blocks_per_cu<1>(ctx, out);
+    case 2: return fused_blocks_per_cu<2>(ctx, out);
+    case 3: return fused_blocks_per_cu<3>(ctx, out);
+    case 4: return fused_blocks_per_cu<4>(ctx, out);
+    case 5: return fused_blocks_per_cu<5>(ctx, out);
+    case 6: return fused_blocks_per_cu<6>(ctx, out);
+    case 7: return fused_blocks_per_cu<7>(ctx, out);
+    default: return fused_blocks_per_cu<8>(ctx, out);
+  }
+}
+
+template <int TR>
+static int launch_fused(rt_ctx* ctx, const ProjParams& p, unsigned grid) {
+  hipLaunchKernelGGL((project_fused_kernel<TR>), dim3(grid), dim3(PT), fused_lds<TR>(), ctx->stream, p);
   RT_HIP_CHECK(ctx, hipGetLastError());
   return RT_OK;
 }
@@ -394,13 +420,29 @@ int rt_project_fused(rt_ctx* ctx, const int64_t* indptr, const int64_t* indices,
   p.data = data; p.d_es = d_es; p.d_bs = d_bs;
   p.V = V; p.ldv = ldv; p.N = N; p.r = (int)r; p.B = (int)B;
   const int tr = (int)((r + 15) / 16), rp = tr * 16;
-  const long slots = 4L * ctx->num_cus;   // a few workgroups per CU so that gather and MFMA phases overlap
-  long S = (slots + B - 1) / B;
+  // DoF ranges per value vector: about two rounds of resident workgroups (so that gather and MFMA phases of
+  // different workgroups overlap), chosen so that the LAST round is full too - 120 vectors x 9 ranges on 512
+  // resident workgroups ran 2.1 rounds' worth of work in 3 rounds (C4's projection at 0.36 of the MFMA peak next
+  // to C5's 0.51 with 32 x 32 = exactly two rounds); 120 x 8 = 960 fills 2 rounds to 94 %.
+  int per_cu = 1;
+  int rc0 = fused_blocks_per_cu(ctx, tr, &per_cu);
+  if (rc0 != RT_OK) return rc0;
+  const long resident = (long)per_cu * ctx->num_cus;
   const long stages = (N + PK - 1) / PK;
-  if (S > stages / 8) S = stages / 8;     // at least 8 stages per workgroup
-  if (S < 1) S = 1;
-  p.k_per_split = ((N + S - 1) / S + PK - 1) / PK * PK;
-  S = (N + p.k_per_split - 1) / p.k_per_split;
+  long s_hi = (2 * resident + B - 1) / B;
+  if (s_hi > stages / 8) s_hi = stages / 8;   // at least 8 stages per workgroup
+  if (s_hi < 1) s_hi = 1;
+  const long s_lo = s_hi / 2 > 1 ? s_hi / 2 : 1;
+  long S = s_hi, kps = 0;
+  double best = -1.0;
+  for (long cand = s_lo; cand <= s_hi; ++cand) {
+    const long per = ((N + cand - 1) / cand + PK - 1) / PK * PK;
+    const long s_eff = (N + per - 1) / per;
+    const long g = B * s_eff, rounds = (g + resident - 1) / resident;
+    const double fill = (double)g / (double)(rounds * resident);
+    if (fill >= best) { best = fill; S = s_eff; kps = per; }   // ties: more, smaller ranges
+  }
+  p.k_per_split = kps;
   p.S = (int)S;
   void* slab = nullptr;
   const size_t slab_bytes = (sizeof(double) * (size_t)B * S * r * r + 255) / 256 * 256;
