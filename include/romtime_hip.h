@@ -59,6 +59,12 @@ int rt_ctx_set_profile(rt_ctx* ctx, int on);
  * cannot keep ahead of the device.  The call then returns only when the sweep has finished. */
 int rt_ctx_set_option(rt_ctx* ctx, const char* name, int value);
 int rt_last_gemm_ms(rt_ctx* ctx, double* ms);
+/* Event counters kept on the device by the kernels themselves (nothing on the hot path waits for them); reading one
+ * synchronises the ctx stream.  Names: "eig_timeouts" (hand-offs of the small eigensolver that hit their wall-clock
+ * bound: results of that call were invalid and the caller took another route), "eig_one_xcd" / "eig_general_form"
+ * (tridiagonalisations that ran each hand-off form), "sweep_newton_iterations", "sweep_restarts",
+ * "sweep_lu_fallbacks", "sweep_solves" (the four numbers of rt_last_sweep_stats). */
+int rt_ctx_get_counter(rt_ctx* ctx, const char* name, int64_t* value);
 /* The same for the most recent launch of the snapshot Gram kernel (rt_gram, n >= 97, long X): its own event pair,
  * so it can be read at the end of a POD step, after the GEMMs that followed it, without holding the host back. */
 int rt_last_gram_ms(rt_ctx* ctx, double* ms);
@@ -191,6 +197,10 @@ typedef struct {
  * b_N = M_N (2u^n - u^{n-1}/2) + dt Zf^T F_rhs;  u* = 2u^n - u^{n-1} (BDF2) or u^n;  zero initial condition.
  * No quantity of size N_h is touched.  uN_out: n_mu x nt x r (device). */
 int rt_hrom_bdf_sweep(rt_ctx* ctx, const rt_hsweep_desc* desc, double* uN_out);
+/* How the reduced systems of the most recent sweep on this ctx were solved (the reference calls GMRES once per step,
+ * rom.py:492; here K_N^-1 is tracked from step to step): stats4 = { Newton-Schulz iterations, systems restarted from
+ * K^T/(|K|_1 |K|_inf), systems handed to the pivoted LU, systems solved }.  Synchronises the ctx stream. */
+int rt_last_sweep_stats(rt_ctx* ctx, int64_t* stats4);
 
 /* ---- small symmetric eigenproblem of the Gram matrix, on the device (3 <= n <= 1024) ---------- */
 /* Householder tridiagonalisation (32 cooperating workgroups, 128 for n > 512; matrix resident in LDS) + Sturm

@@ -34,6 +34,8 @@ SIGNATURES = {
     "rt_ctx_set_option": (_int, [_p, C.c_char_p, _int]),
     "rt_last_gemm_ms": (_int, [_p, C.POINTER(C.c_double)]),
     "rt_last_gram_ms": (_int, [_p, C.POINTER(C.c_double)]),
+    "rt_ctx_get_counter": (_int, [_p, C.c_char_p, C.POINTER(_i64)]),
+    "rt_last_sweep_stats": (_int, [_p, C.POINTER(_i64)]),
     "rt_gram": (_int, [_p, _p, _i64, _i64, _i64, _int, _p]),
     "rt_gram_scale": (_int, [_p, _p, _i64, _p, _int, _p]),
     "rt_gemm_tn": (_int, [_p, _p, _i64, _int, _p, _i64, _int, _i64, _i64, _i64, _p, _i64]),
@@ -120,6 +122,7 @@ class Context:
         if rc != RT_OK:
             raise RomtimeHipError(f"rt_ctx_create(device={device}) failed with {rc}")
         self.handle = h
+        self.options = {}
 
     def __del__(self):
         try:
@@ -151,6 +154,7 @@ class Context:
 
     def set_option(self, name: str, value: int):
         self.check(self.lib.rt_ctx_set_option(self.handle, name.encode(), int(value)), "rt_ctx_set_option")
+        self.options[name] = int(value)
 
     def set_profile(self, on: bool):
         self.profiling = bool(on)
@@ -168,6 +172,18 @@ class Context:
         if self.lib.rt_last_gram_ms(self.handle, C.byref(out)) != 0:
             return float("nan")
         return out.value
+
+    def counter(self, name: str) -> int:
+        """Device-side event counter (rt_ctx_get_counter); synchronises the stream."""
+        out = _i64()
+        self.check(self.lib.rt_ctx_get_counter(self.handle, name.encode(), C.byref(out)), "rt_ctx_get_counter")
+        return int(out.value)
+
+    def sweep_stats(self) -> dict:
+        """How the most recent online sweep solved its reduced systems (rt_last_sweep_stats)."""
+        buf = (_i64 * 4)()
+        self.check(self.lib.rt_last_sweep_stats(self.handle, buf), "rt_last_sweep_stats")
+        return dict(newton_iterations=int(buf[0]), restarts=int(buf[1]), lu_fallbacks=int(buf[2]), solves=int(buf[3]))
 
     def launch_info(self):
         buf = (_i64 * 3)()

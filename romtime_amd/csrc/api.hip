@@ -151,12 +151,21 @@ __global__ __launch_bounds__(256) void copy_kernel(double4* __restrict__ dst, co
 
 int rt_scratch(rt_ctx* ctx, size_t bytes, void** out) { return grow(ctx, &ctx->scratch, &ctx->scratch_bytes, bytes, out); }
 int rt_scratch2(rt_ctx* ctx, size_t bytes, void** out) {
+  ++ctx->scratch2_gen;  // the arena changes hands: state an earlier call left in it (the eigensolver's reflectors) is void
   return grow(ctx, &ctx->scratch2, &ctx->scratch2_bytes, bytes, out);
+}
+
+int rt_func_lds(rt_ctx* ctx, const void* fn, int bytes) {
+  for (const void* f : ctx->lds_done)
+    if (f == fn) return RT_OK;
+  RT_HIP_CHECK(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  ctx->lds_done.push_back(fn);
+  return RT_OK;
 }
 
 extern "C" {
 
-int rt_version(void) { return 100; }
+int rt_version(void) { return 200; }
 
 int rt_ctx_create(rt_ctx** out, int device) {
   if (!out) return RT_ERR_ARG;
@@ -169,6 +178,11 @@ int rt_ctx_create(rt_ctx** out, int device) {
   ctx->device = device;
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+  if (hipMalloc(reinterpret_cast<void**>(&ctx->dev_counters), sizeof(long) * RT_N_COUNTERS) != hipSuccess ||
+      hipMemset(ctx->dev_counters, 0, sizeof(long) * RT_N_COUNTERS) != hipSuccess) {
+    delete ctx;
+    return RT_ERR_HIP;
+  }
   *out = ctx;
   return RT_OK;
 }
@@ -179,6 +193,7 @@ void rt_ctx_destroy(rt_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->scratch2) (void)hipFree(ctx->scratch2);
+  if (ctx->dev_counters) (void)hipFree(ctx->dev_counters);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->gev0) (void)hipEventDestroy(ctx->gev0);
@@ -221,6 +236,34 @@ int rt_ctx_set_option(rt_ctx* ctx, const char* name, int value) {
   }
   ctx->err = "rt_ctx_set_option: unknown option " + key;
   return RT_ERR_ARG;
+}
+
+int rt_ctx_get_counter(rt_ctx* ctx, const char* name, int64_t* value) {
+  if (!ctx || !name || !value) return RT_ERR_ARG;
+  const std::string key(name);
+  static const struct { const char* name; int slot; } table[] = {
+      {"eig_timeouts", RT_CNT_EIG_TIMEOUT}, {"eig_general_form", RT_CNT_EIG_GENERAL_FORM},
+      {"eig_one_xcd", RT_CNT_EIG_ONE_XCD}, {"sweep_newton_iterations", RT_CNT_NS_ITER},
+      {"sweep_restarts", RT_CNT_NS_RESTART}, {"sweep_lu_fallbacks", RT_CNT_LU_FALLBACK}, {"sweep_solves", RT_CNT_SOLVES}};
+  for (const auto& t : table)
+    if (key == t.name) {
+      long host = 0;
+      RT_HIP_CHECK(ctx, hipMemcpyAsync(&host, ctx->dev_counters + t.slot, sizeof(long), hipMemcpyDeviceToHost, ctx->stream));
+      RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+      *value = host;
+      return RT_OK;
+    }
+  ctx->err = "rt_ctx_get_counter: unknown counter " + key;
+  return RT_ERR_ARG;
+}
+
+int rt_last_sweep_stats(rt_ctx* ctx, int64_t* stats4) {
+  if (!ctx || !stats4) return RT_ERR_ARG;
+  long host[4];
+  RT_HIP_CHECK(ctx, hipMemcpyAsync(host, ctx->dev_counters + RT_CNT_NS_ITER, sizeof(host), hipMemcpyDeviceToHost, ctx->stream));
+  RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 4; ++i) stats4[i] = host[i];
+  return RT_OK;
 }
 
 int rt_ctx_set_profile(rt_ctx* ctx, int on) {

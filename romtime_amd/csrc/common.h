@@ -3,8 +3,11 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 
 #include "../../include/romtime_hip.h"
+
+constexpr int RT_N_COUNTERS = 8;
 
 struct rt_ctx {
   int device = 0;
@@ -28,8 +31,36 @@ struct rt_ctx {
     const double *d = nullptr, *e = nullptr, *V = nullptr, *tau = nullptr;
     int64_t n = 0;
     void* base = nullptr;
+    uint64_t gen = 0;  // scratch2_gen when the reflectors were written: any later user of the arena invalidates them
   } eig;
+  uint64_t scratch2_gen = 0;         // bumped by every rt_scratch2 call (each one hands the arena to a new owner)
+  std::vector<const void*> lds_done; // kernels whose dynamic-LDS limit this ctx has raised (rt_func_lds)
+  // Device-side event counters (hipMalloc'ed with the ctx, bumped by the kernels themselves because the host never
+  // waits for them): rt_ctx_get_counter / rt_last_sweep_stats copy them back.
+  long* dev_counters = nullptr;
 };
+
+// slots of rt_ctx::dev_counters
+enum {
+  RT_CNT_EIG_TIMEOUT = 0,       // hand-offs of the tridiagonalisation that hit the wall-clock bound
+  RT_CNT_EIG_GENERAL_FORM = 1,  // tridiagonalisations that ran the write-through hand-off
+  RT_CNT_EIG_ONE_XCD = 2,       // ... the one-XCD hand-off
+  RT_CNT_NS_ITER = 4,           // online sweep: Newton-Schulz iterations (zeroed at the start of every sweep)
+  RT_CNT_NS_RESTART = 5,        // ... systems restarted from K^T / (|K|_1 |K|_inf)
+  RT_CNT_LU_FALLBACK = 6,       // ... systems handed to the pivoted LU
+  RT_CNT_SOLVES = 7             // ... systems solved
+};
+
+#define RT_TRY(expr)                 \
+  do {                               \
+    const int _rc = (expr);          \
+    if (_rc != RT_OK) return _rc;    \
+  } while (0)
+
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the function object of the CURRENT device.  A ctx is bound
+// to one device (and one host thread), so it raises the limit once per kernel and remembers it; process-wide
+// "done" flags would leave the second GPU of a single-process multi-GPU host at the default 64 KB.
+int rt_func_lds(rt_ctx* ctx, const void* fn, int bytes);
 
 #define RT_HIP_CHECK(ctx, expr)                                                              \
   do {                                                                                       \

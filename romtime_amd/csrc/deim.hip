@@ -375,12 +375,7 @@ extern "C" int rt_deim_greedy(rt_ctx* ctx, const double* Phi, int64_t N, int64_t
   // residual columns, then the columns of the block are finished one by one against at most BLK-1
   // in-block columns.  HBM traffic drops from ~4 N m^2 to ~4 N m^2 / BLK + 4 N m (BLK + 7) bytes.
   long* idxp = reinterpret_cast<long*>(idx);
-  static bool attr_set = false;
-  if (!attr_set) {
-    RT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&deim_phase_a_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 1024 * BLK * 8));
-    attr_set = true;
-  }
+  RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&deim_phase_a_kernel), 1024 * BLK * 8));
   for (int k0 = 0; k0 < (int)m; k0 += BLK) {
     const int nb = ((int)m - k0 < BLK) ? (int)m - k0 : BLK;
     if (k0 > 0) {

@@ -165,12 +165,7 @@ template <int MT, int NT, bool KCA, bool KCB, bool SKINNY = false>
 int launch(rt_ctx* ctx, const GemmParams& p, int grid) {
   constexpr int BM = SKINNY ? 64 * MT : 32 * MT, BNP = SKINNY ? 64 : 32 * NT;
   constexpr size_t lds = sizeof(double) * 2 * (Panel<BM, KCA>::LDS + Panel<BNP, KCB>::LDS);
-  static bool attr_set = false;
-  if (!attr_set) {
-    RT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f64_mfma_kernel<MT, NT, KCA, KCB, SKINNY>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&gemm_f64_mfma_kernel<MT, NT, KCA, KCB, SKINNY>), (int)lds));
   hipLaunchKernelGGL((gemm_f64_mfma_kernel<MT, NT, KCA, KCB, SKINNY>), dim3(grid), dim3(NTHREADS), lds, ctx->stream, p);
   RT_HIP_CHECK(ctx, hipGetLastError());
   return RT_OK;

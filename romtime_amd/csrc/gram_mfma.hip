@@ -205,12 +205,7 @@ __global__ void gram_reduce_kernel(const GramReduceParams p) {
 template <bool KC, bool DIAG>
 int launch_gram(rt_ctx* ctx, const GramParams& p, int grid) {
   constexpr size_t lds = sizeof(double) * (DIAG ? 2 : 4) * Panel<BT, KC, GT>::LDS;
-  static bool attr_set = false;
-  if (!attr_set) {
-    RT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&gram128_kernel<KC, DIAG>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    attr_set = true;
-  }
+  RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&gram128_kernel<KC, DIAG>), (int)lds));
   hipLaunchKernelGGL((gram128_kernel<KC, DIAG>), dim3(grid), dim3(GT), lds, ctx->stream, p);
   RT_HIP_CHECK(ctx, hipGetLastError());
   return RT_OK;

@@ -374,10 +374,9 @@ static constexpr size_t fused_lds() {
 // workgroups of project_fused_kernel<TR> that fit one CU (LDS and registers), asked of the runtime once per TR
 template <int TR>
 static int fused_blocks_per_cu(rt_ctx* ctx, int* out) {
-  static int cached = 0;
+  static int cached = 0;  // occupancy is a property of the kernel on gfx950, the same on every device of the node
+  RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&project_fused_kernel<TR>), 104 * 1024));
   if (cached == 0) {
-    RT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&project_fused_kernel<TR>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 104 * 1024));
     int nb = 0;
     RT_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, project_fused_kernel<TR>, PT, fused_lds<TR>()));
     cached = nb > 0 ? nb : 1;

@@ -107,13 +107,8 @@ extern "C" int rt_rank_update(rt_ctx* ctx, const double* Ysrc, int64_t ldys, con
   }
   RuParams p{Ysrc, X, T, colscale, Ydst, (long)N, (long)ldys, (long)ldx, (long)ldt, (long)ldyd, (int)n, (int)k, alpha};
   const size_t lds = sizeof(double) * ((size_t)k * RU_COLS + (size_t)RU_ROWS * k);
-  static bool attr_set = false;
-  if (!attr_set) {
-    RT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&rank_update_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)(sizeof(double) * RU_KMAX * (RU_COLS + RU_ROWS))));
-    attr_set = true;
-  }
+  RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&rank_update_kernel),
+                     (int)(sizeof(double) * RU_KMAX * (RU_COLS + RU_ROWS))));
   const long stages = (N + RU_ROWS - 1) / RU_ROWS;
   const unsigned gy = (unsigned)((n + RU_COLS - 1) / RU_COLS);
   long gx = (long)ctx->num_cus * 8 / gy;

@@ -26,8 +26,9 @@ constexpr int SOLVE_BATCH = 4;
 
 __global__ __launch_bounds__(SOLVE_THREADS) void dense_solve_kernel(const double* __restrict__ K,
                                                                     double* __restrict__ rhs, int r, int parts,
-                                                                    int* info, const int* only_if) {
+                                                                    int* info, const int* only_if, long* counters) {
   if (only_if && only_if[blockIdx.x] == 0) return;  // fallback launch: only the systems another solver gave up on
+  if (only_if && threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[RT_CNT_LU_FALLBACK]), 1ull);
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int lda = r | 1;  // odd leading dimension: column walks hit distinct banks
   double* A = sm;         // r x lda
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(NS_THREADS) void newton_solve_kernel(const double* 
                                                                   double* __restrict__ Xinv,
                                                                   double* __restrict__ rhs, int r, int S,
                                                                   int have_prev, int* __restrict__ info,
-                                                                  const rt_newton_rhs rq) {
+                                                                  const rt_newton_rhs rq, long* counters) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int tr = (r + 15) / 16, rp = tr * 16, ntile = tr * tr;
   double* sK = sm;                    // [rp][S], padded with the identity
@@ -246,7 +247,9 @@ __global__ __launch_bounds__(NS_THREADS) void newton_solve_kernel(const double* 
 
   int status = RT_WARN_SINGULAR;
   bool restarted = !have_prev;
+  int n_iter = 0, n_restart = 0;
   for (int it = 0; it < NS_MAX_ITER; ++it) {
+    ++n_iter;
     // T = K X and the residual ||I - T||_F
     double part = 0.0;
     d4 acc[NSQ];
@@ -269,6 +272,7 @@ __global__ __launch_bounds__(NS_THREADS) void newton_solve_kernel(const double* 
     if (res != res) break;  // NaN: singular to working precision (or bad input)
     if (!restarted && !(res < 0.7)) {  // the carried inverse is no contraction for this K: safe start instead
       restarted = true;
+      n_restart = 1;
       restart();
       continue;
     }
@@ -294,6 +298,11 @@ __global__ __launch_bounds__(NS_THREADS) void newton_solve_kernel(const double* 
     }
   }
 
+  if (tid == 0) {  // rt_last_sweep_stats
+    atomicAdd(reinterpret_cast<unsigned long long*>(&counters[RT_CNT_NS_ITER]), (unsigned long long)n_iter);
+    atomicAdd(reinterpret_cast<unsigned long long*>(&counters[RT_CNT_NS_RESTART]), (unsigned long long)n_restart);
+    atomicAdd(reinterpret_cast<unsigned long long*>(&counters[RT_CNT_SOLVES]), 1ull);
+  }
   if (status != 0) {  // leave rhs for the LU fallback and make the next call start afresh
     for (int i = wid; i < r; i += NS_THREADS / 64)
       for (int j = lane; j < r; j += 64) Xb[i * r + j] = 0.0;
@@ -344,16 +353,11 @@ static int dense_solve_launch(rt_ctx* ctx, double* K, double* rhs, int64_t r, in
   }
   const int lda = (int)r | 1;
   const size_t lds = sizeof(double) * ((size_t)r * lda + r);
-  static bool attr_set = false;
-  if (!attr_set) {
-    RT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&dense_solve_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024));
-    attr_set = true;
-  }
+  RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&dense_solve_kernel), 140 * 1024));
   int parts = SOLVE_THREADS / (int)r;  // threads per row
   if (parts > 8) parts = 8;
   hipLaunchKernelGGL(dense_solve_kernel, dim3((unsigned)B), dim3(SOLVE_THREADS), lds, ctx->stream, K, rhs, (int)r,
-                     parts, info, only_if);
+                     parts, info, only_if, ctx->dev_counters);
   RT_HIP_CHECK(ctx, hipGetLastError());
   return RT_OK;
 }
@@ -369,16 +373,11 @@ int rt_newton_solve_batched(rt_ctx* ctx, const double* K, double* Xinv, double* 
   while (S % 4 != 2) ++S;  // 2 S == 4 (mod 8): the 16 rows of an A-operand read fall in distinct LDS banks
   const size_t lds = sizeof(double) * 3 * (size_t)rp * S;
   if (lds > 156 * 1024) return RT_ERR_UNSUPPORTED;  // + 3 KB of static LDS = the CU's 160 KB
-  static bool attr_set = false;
-  if (!attr_set) {
-    RT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&newton_solve_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024));
-    attr_set = true;
-  }
+  RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&newton_solve_kernel), 156 * 1024));
   rt_newton_rhs rq{};
   if (recipe) rq = *recipe;
   hipLaunchKernelGGL(newton_solve_kernel, dim3((unsigned)B), dim3(NS_THREADS), lds, ctx->stream, K, Xinv, rhs, (int)r, S,
-                     have_prev, info, rq);
+                     have_prev, info, rq, ctx->dev_counters);
   RT_HIP_CHECK(ctx, hipGetLastError());
   return RT_OK;
 }

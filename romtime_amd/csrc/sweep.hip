@@ -192,6 +192,7 @@ extern "C" int rt_rom_bdf_sweep(rt_ctx* ctx, const rt_sweep_desc* d, double* uN_
 
   RT_HIP_CHECK(ctx, hipMemsetAsync(un, 0, sizeof(double) * B * r, st));
   RT_HIP_CHECK(ctx, hipMemsetAsync(unm1, 0, sizeof(double) * B * r, st));
+  RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->dev_counters + RT_CNT_NS_ITER, 0, sizeof(long) * 4, st));  // rt_last_sweep_stats
   RT_HIP_CHECK(ctx, hipMemsetAsync(uh, 0, sizeof(double) * B * N, st));
   RT_HIP_CHECK(ctx, hipMemsetAsync(uhp, 0, sizeof(double) * B * N, st));
   hipLaunchKernelGGL(sweep_rows_kernel, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, st,
@@ -278,6 +279,7 @@ extern "C" int rt_hrom_bdf_sweep(rt_ctx* ctx, const rt_hsweep_desc* d, double* u
   long* ctr = reinterpret_cast<long*>(b8 + oCtr);
   RT_HIP_CHECK(ctx, hipMemsetAsync(un, 0, sizeof(double) * B * r, st));
   RT_HIP_CHECK(ctx, hipMemsetAsync(unm1, 0, sizeof(double) * B * r, st));
+  RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->dev_counters + RT_CNT_NS_ITER, 0, sizeof(long) * 4, st));  // rt_last_sweep_stats
 
   auto advance = [&](long next, int do_store) {  // close step next-1 (if any) and prepare the rows of step `next`
     const bool has_next = next < nt;
@@ -333,7 +335,13 @@ extern "C" int rt_hrom_bdf_sweep(rt_ctx* ctx, const rt_hsweep_desc* d, double* u
         ctx->err = "rt_hrom_bdf_sweep: capturing the step graph failed";
         return rc != RT_OK ? rc : RT_ERR_HIP;
       }
-      RT_HIP_CHECK(ctx, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+      {
+        const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        if (ie != hipSuccess) {
+          (void)hipGraphDestroy(graph);
+          RT_HIP_CHECK(ctx, ie);
+        }
+      }
       hipError_t le = hipSuccess;
       for (long s2 = 1; s2 < nt && le == hipSuccess; ++s2) le = hipGraphLaunch(exec, st);
       const hipError_t se = hipStreamSynchronize(st);  // the executable graph owns the launch arguments: keep it until done

@@ -48,6 +48,7 @@ struct TriParams {
   int n;
   int tw;            // cooperating workgroups
   int spread;        // 1: launched as 8 tw blocks, only the blocks with blockIdx % 8 == 0 work (they share an XCD)
+  long* counters;    // rt_ctx::dev_counters: which hand-off form ran, and time-outs (rt_ctx_get_counter)
 };
 
 __device__ __forceinline__ void st_wt(double* p, double v) {
@@ -75,7 +76,7 @@ __device__ __forceinline__ double ld_wt(const double* p) {
 // Arrival at a hand-off = storing the hop number into the workgroup's own slot; one wave waits until every slot
 // holds >= want (the TW slots are one or two 128-byte lines: one load per poll, and no read-modify-write that 32
 // arrivals would queue up behind - a shared counter cost 0.6 us per hop more).  Called by a whole wave; false if
-// the error word is set or 2 s pass.
+// the error word is set or 0.5 s pass.
 __device__ __forceinline__ bool poll_slots(int* slots, int TW, int want, int* err) {
   const int lane = threadIdx.x & 63;
   const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();  // 100 MHz
@@ -88,7 +89,7 @@ __device__ __forceinline__ bool poll_slots(int* slots, int TW, int want, int* er
     if (__builtin_amdgcn_ballot_w64(f < want) == 0) return true;
     __builtin_amdgcn_s_sleep(1);
     if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
-    if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull) {
+    if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) {  // 0.5 s at 100 MHz
       __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return false;
     }
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
     for (int w = 1; w < TW; ++w)
       same &= (__hip_atomic_load(&p.flags[8 + w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == mine);
     s_one = same;
+    if (wg == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&p.counters[same ? RT_CNT_EIG_ONE_XCD : RT_CNT_EIG_GENERAL_FORM]), 1ull);
   }
   __syncthreads();
   const bool one_xcd = s_one != 0;
@@ -364,8 +366,11 @@ constexpr int BIS_NS = 2;  // shifts per lane
 template <int NM>
 __global__ __launch_bounds__(256) void symeig_bisect_kernel(const double* __restrict__ d, const double* __restrict__ e,
                                                             int n, int first, int count, double* __restrict__ lam,
-                                                            const int* flags, int* status) {
-  if (status && blockIdx.x == 0 && threadIdx.x == 0) *status = flags[3];
+                                                            const int* flags, int* status, long* counters) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    if (status) *status = flags[3];
+    if (flags[3]) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[RT_CNT_EIG_TIMEOUT]), 1ull);
+  }
   __shared__ double sd[NM], se2[NM];
   __shared__ int s_first[2][4];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6, half = wid & 1;
@@ -655,41 +660,54 @@ extern "C" int rt_sym_eig_values_part(rt_ctx* ctx, const double* G, int64_t n, i
   tp.V = reinterpret_cast<double*>(b8 + oV); tp.P = reinterpret_cast<double*>(b8 + oP);
   tp.tau = reinterpret_cast<double*>(b8 + oT); tp.d = reinterpret_cast<double*>(b8 + oD);
   tp.e = reinterpret_cast<double*>(b8 + oE); tp.flags = reinterpret_cast<int*>(b8 + oF);
+  tp.counters = ctx->dev_counters;
   hipStream_t st = ctx->stream;
   hipLaunchKernelGGL(symeig_init_kernel, dim3(1), dim3(256), 0, st, tp.flags, tp.tau, (int)n);
 
   const int RB = (int)((n + tw - 1) / tw);
   const size_t lds = sizeof(double) * ((size_t)RB * n + 4 * n + 16);  // A slab | v (x2) | w | row
-  static bool attr_set = false;
-  if (!attr_set) {
-    RT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&symeig_tridiag_kernel<512>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    RT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&symeig_tridiag_kernel<1024>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-    attr_set = true;
+  RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&symeig_tridiag_kernel<512>), 150 * 1024));
+  RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&symeig_tridiag_kernel<1024>), 150 * 1024));
+  {
+    // The tw workers spin on each other: all of them must be resident at once.  Ask the runtime how many of these
+    // workgroups a CU holds (1: the slab takes most of its LDS) and refuse up front what the device cannot hold,
+    // instead of finding out through the hand-off's wall-clock bound.
+    int per_cu = 0;
+    if (large)
+      RT_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, symeig_tridiag_kernel<1024>, TT, lds));
+    else
+      RT_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, symeig_tridiag_kernel<512>, TT, lds));
+    if ((long)per_cu * ctx->num_cus < tw) {
+      ctx->err = "rt_sym_eig_values: the device cannot keep all cooperating workgroups resident";
+      return RT_ERR_UNSUPPORTED;
+    }
   }
   const dim3 bgrid((unsigned)((count + 1) / 2));
   if (large) {
     hipLaunchKernelGGL(symeig_tridiag_kernel<1024>, dim3(tw), dim3(TT), lds, st, tp);
     RT_HIP_CHECK(ctx, hipGetLastError());
     hipLaunchKernelGGL(symeig_bisect_kernel<1024>, bgrid, dim3(256), 0, st, tp.d, tp.e, (int)n, (int)first, (int)count,
-                       lam, tp.flags, status);
+                       lam, tp.flags, status, ctx->dev_counters);
   } else {
     hipLaunchKernelGGL(symeig_tridiag_kernel<512>, dim3(tp.spread ? 8 * tw : tw), dim3(TT), lds, st, tp);
     RT_HIP_CHECK(ctx, hipGetLastError());
     hipLaunchKernelGGL(symeig_bisect_kernel<512>, bgrid, dim3(256), 0, st, tp.d, tp.e, (int)n, (int)first, (int)count,
-                       lam, tp.flags, status);
+                       lam, tp.flags, status, ctx->dev_counters);
   }
   RT_HIP_CHECK(ctx, hipGetLastError());
   ctx->eig.d = tp.d; ctx->eig.e = tp.e; ctx->eig.V = tp.V; ctx->eig.tau = tp.tau; ctx->eig.n = n; ctx->eig.base = base;
+  ctx->eig.gen = ctx->scratch2_gen;
   return RT_OK;
 }
 
 extern "C" int rt_sym_eig_vectors(rt_ctx* ctx, int64_t n, int64_t k, const double* lam, double* W) {
   if (!ctx) return RT_ERR_ARG;
   RT_ARG_CHECK(ctx, lam && W && k >= 1 && k <= n);
-  if (ctx->eig.n != n || ctx->eig.base == nullptr || ctx->eig.base != ctx->scratch2) {
-    ctx->err = "rt_sym_eig_vectors: must directly follow rt_sym_eig_values on the same ctx and matrix";
+  // the reflectors live in the composite arena: any operator that has carved it since (greedy, projections, the
+  // sweeps - every rt_scratch2 call bumps the generation) has overwritten them
+  if (ctx->eig.n != n || ctx->eig.base == nullptr || ctx->eig.base != ctx->scratch2 || ctx->eig.gen != ctx->scratch2_gen) {
+    ctx->err = "rt_sym_eig_vectors: must follow rt_sym_eig_values on the same ctx and matrix with no other composite "
+               "operator (greedy, projection, sweep) in between";
     return RT_ERR_ARG;
   }
   VecParams vp;
@@ -700,14 +718,8 @@ extern "C" int rt_sym_eig_vectors(rt_ctx* ctx, int64_t n, int64_t k, const doubl
   int rc = rt_scratch(ctx, sizeof(double) * 6 * (size_t)nblk, &cbuf);  // leaf arena: free between the two calls
   if (rc != RT_OK) return rc;
   vp.C = static_cast<const double*>(cbuf);
-  static bool vattr_set = false;
-  if (!vattr_set) {
-    RT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&symeig_vectors_kernel<512>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    RT_HIP_CHECK(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&symeig_vectors_kernel<1024>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
-    vattr_set = true;
-  }
+  RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&symeig_vectors_kernel<512>), 80 * 1024));
+  RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&symeig_vectors_kernel<1024>), 80 * 1024));
   if (n > 512) {
     const size_t vlds = sizeof(double) * (8 * 1024 + 8) + 1024;
     hipLaunchKernelGGL(symeig_wy_kernel<1024>, dim3((unsigned)nblk), dim3(64), 0, ctx->stream, vp.V, (int)n,

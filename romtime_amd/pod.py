@@ -150,8 +150,6 @@ class _SmallEig:
     (rt_sym_eig_values / rt_sym_eig_vectors, Rayleigh-Ritz polish on G when kept eigenvalues are
     closer than RR_GAP * lam_1); other sizes use host LAPACK."""
 
-    _retried_general_form = False
-
     def __init__(self, G: torch.Tensor, extra=(), group=None, ahead=None):
         """``ahead(self)``: device work the caller wants enqueued BEFORE the eigenvalues reach the host (it may
         use ``raw_vectors``); the eigenvalues then travel on a side stream while that work runs."""
@@ -179,16 +177,25 @@ class _SmallEig:
             else:
                 head = _fetch_beside(head, lambda: ahead(self))
             self.lam, self.extra = head[: self.n], head[self.n + 1:]
-            if int(head[self.n]) != 0 and not _SmallEig._retried_general_form:
-                # the one-XCD form needs every CU of one XCD; something else held some (another process on this
-                # GPU): switch this context to the general form for good and redo the decomposition once
-                _SmallEig._retried_general_form = True
-                _lib.Context.current().set_option("eig_one_xcd", 0)
-                self.__init__(G, extra=extra, group=group, ahead=ahead)
-                return
             if int(head[self.n]) != 0:
-                raise _lib.RomtimeHipError("rt_sym_eig_values: inter-workgroup hand-off timed out")
-        else:
+                # A hand-off of the cooperative tridiagonalisation hit its wall-clock bound: some of its workgroups
+                # were not resident (another stream or process held CUs).  Nothing computed from it is used.  This
+                # ctx (one per thread and device) leaves the one-XCD form for good and the decomposition is redone
+                # once in the general form; if that times out as well, this call takes host LAPACK.  Both are
+                # reported: warnings here, "eig_timeouts" through rt_ctx_get_counter.
+                import warnings
+
+                ctx = _lib.Context.current()
+                if ctx.options.get("eig_one_xcd", 1):
+                    warnings.warn("romtime_amd: eigensolver hand-off timed out in the one-XCD form; this context "
+                                  "now uses the general form (rt_ctx_set_option eig_one_xcd=0)", RuntimeWarning)
+                    ctx.set_option("eig_one_xcd", 0)
+                    self.__init__(G, extra=extra, group=group, ahead=ahead)
+                    return
+                warnings.warn("romtime_amd: eigensolver hand-off timed out in the general form; host LAPACK takes "
+                              "this eigenproblem", RuntimeWarning)
+                self.on_device, self.group = False, None
+        if not self.on_device:
             Gh = G.cpu().numpy()
             self.extra = np.concatenate([np.atleast_1d(e.cpu().numpy()).astype(float) for e in extra]) if extra else np.zeros(0)
             self.lam, self.W = _eigh_desc(Gh)
@@ -364,7 +371,7 @@ def pod_device(X: torch.Tensor, num=None, tol=None, normalize=True, passes=None,
     _AHEAD_DROPPED[ahead_key] = bool(passes != 1 or r != ahead_key[1])
 
     if passes == 1:
-        if r > 0 and r == k_ahead and "Q" in ahead_out and eig.well_separated(r):
+        if r > 0 and r == k_ahead and "Q" in ahead_out and eig.on_device and eig.well_separated(r):
             Q = ahead_out["Q"]  # enqueued before the eigenvalues arrived, and they confirm it
             VT = np.ascontiguousarray(eig.raw_vectors(r).cpu().numpy().T) if want_vt else None
         elif r > 0:
@@ -424,14 +431,19 @@ def _pod_deflated(X, eig0, colnorm, normalize, num, tol, group, want_vt):
     s_acc, Q_acc, W_acc = [], [], []
     # with ``num`` alone the basis never has more than num columns: the levels write straight into it
     cap = int(min(num, n)) if (num and not tol) else None
-    Qbuf = torch.empty((X.shape[0], cap), dtype=torch.float64, device=dev) if cap else None
+    # zeros: with ``num`` above the numerical rank and an exactly zero tail the levels stop before the buffer is full,
+    # and the columns never written must be the zero columns the single-pass route returns (_inv_or_zero)
+    Qbuf = torch.zeros((X.shape[0], cap), dtype=torch.float64, device=dev) if cap else None
     levels = 0
     while True:
         levels += 1
         sig = np.sqrt(np.clip(eig.lam, 0.0, None))
         have = sum(len(x) for x in s_acc)
         room = (cap if cap else n) - have
-        k = int(min(max(1, np.count_nonzero(sig >= TWO_PASS_RATIO * sig[0])), room)) if sig[0] > 0 else 0
+        # below n eps sigma_1 the deflated snapshots hold rounding residue, not modes: the numerical rank is reached
+        # and the remaining columns of a ``num`` basis stay zero (what the single-pass route returns too)
+        floor = n * np.finfo(float).eps * s_acc[0][0] if s_acc else 0.0
+        k = int(min(max(1, np.count_nonzero(sig >= TWO_PASS_RATIO * sig[0])), room)) if sig[0] > floor else 0
         if k > 0:
             Z = eig.vectors(k)
             src = X if Xc is None else Xc

@@ -27,7 +27,9 @@ def _worker(rank, world, port, X, kwargs, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from romtime_amd import pod
+        from romtime_amd._lib import Context
 
+        Context.current().set_option("eig_one_xcd", 0)   # the ranks share one GPU: none of them can have a whole XCD
         rows = np.array_split(np.arange(X.shape[0]), world)[rank]
         out = pod.pod_device(torch.from_numpy(X[rows]).cuda(), group=dist.group.WORLD, **kwargs)
         ret[rank] = dict(rows=rows, Q=out["Q"].cpu().numpy(), s=out["s"], energy=out["energy"], r=out["r"],

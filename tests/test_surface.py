@@ -505,6 +505,21 @@ def check_orth_odd_shapes():
     Q, s, e = orth(Z, normalize=False)
     Qr, sr, er = oracle.orth(Z, normalize=False)
     assert Q.shape == Qr.shape == (20, 0) and np.all(s == 0) and np.all(np.isnan(e)) and np.all(np.isnan(er))
+    # ``num`` above the numerical rank with an exactly zero tail (a forcing that vanishes at several times, walked
+    # with normalize=False and num_t, deim.py:390-395): every returned column is finite; the kept directions match
+    # the oracle's and the columns beyond the rank are zero columns on both routes (dgesvd completes the basis with
+    # arbitrary orthonormal vectors there; no caller can depend on them)
+    R = np.zeros((60, 5))
+    R[:, 0] = rng.standard_normal(60)
+    R[:, 3] = 1e-3 * rng.standard_normal(60)
+    for passes in (1, "deflate"):
+        Q, s, e = orth(R, num=4, normalize=False, passes=passes)
+        Qr, sr, er = oracle.orth(R, num=4, normalize=False)
+        assert Q.shape == (60, 4) and np.all(np.isfinite(Q)), passes
+        assert_allclose(s, sr, rtol=0, atol=1e-13 * sr[0])
+        for i in range(2):
+            assert min(np.linalg.norm(Q[:, i] - Qr[:, i]), np.linalg.norm(Q[:, i] + Qr[:, i])) < 1e-9, (passes, i)
+        assert np.all(Q[:, 2:] == 0.0), passes
     if torch.cuda.is_available():
         Xd = torch.from_numpy(rng.standard_normal((500, 8))).cuda()
         Qd, s, e = orth(Xd, num=3)
