@@ -73,9 +73,14 @@ def load_reference():
     dolfin_la.Vector = Vector
     dolfin.cpp = dolfin_cpp
     dolfin_cpp.la = dolfin_la
+    seaborn = types.ModuleType("seaborn")
+    seaborn.set_theme = lambda *a, **k: None  # rom/hrom.py:42 calls it at import
+    import json
+
+    ujson = types.ModuleType("ujson")  # utils.py:214-225 dump_json / read_json: same wire format as json
+    ujson.dump, ujson.load = json.dump, json.load
     for name, mod in [("fenics", fenics), ("dolfin", dolfin), ("dolfin.cpp", dolfin_cpp),
-                      ("dolfin.cpp.la", dolfin_la), ("ujson", types.ModuleType("ujson")),
-                      ("seaborn", types.ModuleType("seaborn"))]:
+                      ("dolfin.cpp.la", dolfin_la), ("ujson", ujson), ("seaborn", seaborn)]:
         sys.modules[name] = mod
     adj = types.ModuleType("adjustText")
     adj.adjust_text = lambda *a, **k: None
@@ -114,9 +119,12 @@ def load_reference():
     import romtime.rom.rom as ref_rom
     import romtime.rom.base as ref_base
     import romtime.utils as ref_utils
+    import romtime.deim.nonlinear as ref_nonlinear
+    import romtime.rom.hrom as ref_hrom
+    import romtime.conventions as ref_conv
 
-    return types.SimpleNamespace(pod=ref_pod, deim=ref_deim, rom=ref_rom, base=ref_base,
-                                 utils=ref_utils, Matrix=Matrix, Vector=Vector)
+    return types.SimpleNamespace(pod=ref_pod, deim=ref_deim, rom=ref_rom, base=ref_base, nonlinear=ref_nonlinear,
+                                 hrom=ref_hrom, conv=ref_conv, utils=ref_utils, Matrix=Matrix, Vector=Vector)
 
 
 # ---------------------------------------------------------------------------
@@ -415,6 +423,242 @@ def gen_sampler(ref, out):
     print("sampler.npz:", arr.shape)
 
 
+# ---------------------------------------------------------------------------
+# tree walks, truncation, reduced-basis construction (a2 / a14) -- the reference's own
+# DiscreteEmpiricalInterpolation.run (deim.py:175-215,279-397), N-MDEIM run / truncate
+# (nonlinear.py:49-104,159-212,405-468), RomConstructor.build_reduced_basis / truncate
+# (rom.py:169-198,276-412) on the closed-form P1 FOM of romtime_amd.testing.mock
+# ---------------------------------------------------------------------------
+WALK_MUS = [dict(alpha_0=0.4, beta=2.0, delta=0.3), dict(alpha_0=1.1, beta=5.5, delta=1.2),
+            dict(alpha_0=1.7, beta=8.0, delta=0.7), dict(alpha_0=0.9, beta=3.3, delta=1.8)]
+WALK_TS = np.linspace(0.2, 5.0, 9)
+
+
+def walk_forcing(x, t, **mu):
+    """A forcing with genuinely (mu, t)-dependent shape: the per-mu time bases span different subspaces, so the
+    mu-level spectrum has no exact multiplicities (the separable forcing of tests/test_deim.py gives sigma = sqrt(n_mu)
+    twice, and then any rotation of the basis is an equally valid answer)."""
+    return (np.sin(mu["beta"] * x * (1.0 + 0.2 * mu["delta"] * t)) * np.exp(-0.3 * t)
+            + mu["alpha_0"] * np.cos(3.0 * x + mu["delta"] * t) + 0.5 * mu["delta"] * x * x * t)
+
+
+def walk_solver():
+    from romtime_amd.testing.mock import MockBurgers
+
+    fom = MockBurgers(domain=dict(L0=1.0, nx=60, T=5.0, nt=20), Lt=lambda t, **mu: 1.0 + 0.1 * mu["delta"] * t)
+    fom.forcing_term = walk_forcing
+    fom.setup()
+    return fom
+
+
+def walk_rich_operator(fom):
+    """(mu, t)-dependent combination of the P1 operators (all on the tridiagonal pattern)."""
+
+    def assemble(mu=None, t=None, entries=None):
+        w = np.sin((1.0 + mu["delta"]) * np.pi * fom.x_at(mu, t) * (1.0 + 0.3 * t)) * mu["alpha_0"]
+        parts = [(1.0, fom.assemble_stiffness(mu, t, entries=entries)),
+                 (1.0 + t * mu["beta"], fom.assemble_mass(mu, t, entries=entries)),
+                 (mu["delta"], fom.assemble_convection(mu, t, entries=entries)),
+                 (1.0, fom.assemble_trilinear(mu, t, w, entries=entries))]
+        out = parts[0][1] * parts[0][0]
+        for c, a in parts[1:]:
+            out = out + c * a
+        if entries is not None:                      # Dirichlet rows: the combination would give 1+..., keep 1 / 0
+            for k, (i, j) in enumerate(entries):
+                if i in (0, fom.Nh - 1):
+                    out[k] = 1.0 if i == j else 0.0
+            return out
+        out = out.tolil()
+        for i in (0, fom.Nh - 1):
+            out[i, :] = 0.0
+            out[i, i] = 1.0
+        return out.tocsr()
+
+    return assemble
+
+
+def walk_state_operator(fom):
+    """State-dependent operator with (mu, t) dependence: trilinear(u_n) + nonlinear lifting(mu, t)."""
+
+    def assemble(mu=None, t=None, u_n=None, entries=None):
+        mu2 = dict(mu, omega=1.0 + mu["beta"])
+        a = fom.assemble_trilinear(mu2, t, u_n, entries=entries)
+        b = fom.assemble_nonlinear_lifting(mu2, t, entries=entries)
+        if entries is not None:
+            out = a + b
+            for k, (i, j) in enumerate(entries):
+                if i in (0, fom.Nh - 1):
+                    out[k] = 1.0 if i == j else 0.0
+            return out
+        out = (a + b).tolil()
+        for i in (0, fom.Nh - 1):
+            out[i, :] = 0.0
+            out[i, i] = 1.0
+        return out.tocsr()
+
+    return assemble
+
+
+def _as_dolfin(ref, fn):
+    """The reference type-switches on dolfin Matrix (bilinear_to_csr, utils.py:76-93): full assemblies are wrapped
+    in the Matrix stand-in, entry-wise assemblies stay plain arrays."""
+
+    def assemble(**kw):
+        out = fn(**kw)
+        return out if kw.get("entries") is not None else ref.Matrix(out)
+
+    return assemble
+
+
+def _store_report(data, key, red, Stage):
+    off = red.report[Stage.OFFLINE]
+    n_mu = len(red.mu_space[Stage.OFFLINE])
+    data[f"{key}__basis_time"] = np.array([off["basis-shape-time"][i] for i in range(n_mu)])
+    data[f"{key}__after_walk"] = np.array(off["basis-shape-after-tree-walk"])
+    data[f"{key}__final"] = np.array(off["basis-shape-final"])
+    data[f"{key}__spectrum_mu"] = np.asarray(off["spectrum-mu"])
+    data[f"{key}__energy_mu"] = np.asarray(off["energy-mu"])
+    for i in range(n_mu):
+        data[f"{key}__spectrum_time_{i}"] = np.asarray(off["spectrum-time"][i])
+
+
+def _check_well_posed(name, sigmas, kept, thresholds=(1e-7,)):
+    """The fixture must not sit on a knife edge: kept singular values separated, none within 20 % of DROP_TOLERANCE."""
+    s = np.asarray(sigmas)
+    for th in thresholds:
+        assert not np.any((s > 0.8 * th) & (s < 1.25 * th)), (name, "sigma near the drop tolerance", s)
+    k = s[: kept + 1] if kept < len(s) else s[:kept]
+    gaps = np.abs(np.diff(k)) / k[0]
+    return float(gaps.min()) if gaps.size else 1.0
+
+
+def gen_walks(ref, out):
+    Stage = ref.conv.Stage
+    DEIM = ref.deim.DiscreteEmpiricalInterpolation
+    MDEIM = ref.deim.MatrixDiscreteEmpiricalInterpolation
+    NMDEIM = ref.nonlinear.MatrixDiscreteEmpiricalInterpolationNonlinear
+    data = {}
+    fom = walk_solver()
+    params = {"ts": WALK_TS, "num_snapshots": len(WALK_MUS)}
+    data["mus"] = np.array([[m["alpha_0"], m["beta"], m["delta"]] for m in WALK_MUS])
+    data["ts"] = WALK_TS
+
+    # -- DEIM.run on a vector functional, default truncation (drop branch at both levels) and num / tol variants
+    for key, extra in (("deim_default", {}), ("deim_num", {"num_mu": 6, "num_time": 4}),
+                       ("deim_tol", {"tol_mu": 1.0 - 1e-9, "tol_time": 1.0 - 1e-10})):
+        d = DEIM(assemble=fom.assemble_forcing, grid=None, tree_walk_params=dict(params, **extra), name=key)
+        d.setup(rnd=np.random.RandomState(0))
+        d.run(mu_space=[dict(m) for m in WALK_MUS])
+        data[f"{key}__basis_fom"] = d.basis_fom
+        data[f"{key}__sigmas"] = d.sigmas
+        data[f"{key}__dofs"] = np.array([i for (i,) in d.dofs], dtype=np.int64)
+        data[f"{key}__PT_U"] = d.PT_U
+        _store_report(data, key, d, Stage)
+        data[f"{key}__min_gap"] = np.array(_check_well_posed(key, d.sigmas, d.N))
+
+    # -- MDEIM.run: the reference's own acceptance operators (separable -> degenerate spectra) and a rich one
+    ops_m = {"mdeim_stiffness": fom.assemble_stiffness, "mdeim_rich": walk_rich_operator(fom)}
+    for key, fn in ops_m.items():
+        md = MDEIM(assemble=_as_dolfin(ref, fn), grid=None, tree_walk_params=dict(params), name=key)
+        ref.base.Reductor.setup(md, rnd=np.random.RandomState(0))     # MDEIM.setup samples the grid for a topology mu
+        md.rows, md.cols = md.get_matrix_topology(mu=WALK_MUS[0], t=1.0)
+        md.run(mu_space=[dict(m) for m in WALK_MUS])
+        data[f"{key}__rows"] = np.array(md.rows, dtype=np.int64)
+        data[f"{key}__cols"] = np.array(md.cols, dtype=np.int64)
+        data[f"{key}__basis_fom"] = md.basis_fom
+        data[f"{key}__sigmas"] = md.sigmas
+        data[f"{key}__dofs"] = np.array(md.dofs, dtype=np.int64)
+        data[f"{key}__PT_U"] = md.PT_U
+        _store_report(data, key, md, Stage)
+        gaps = np.abs(np.diff(md.sigmas[: md.N + 1])) / md.sigmas[0]
+        data[f"{key}__min_gap"] = np.array(gaps.min() if gaps.size else 1.0)
+
+    # -- N-MDEIM.run (three levels, all normalised) + truncate(n)
+    rng = np.random.RandomState(5)
+    x = np.linspace(0.0, 1.0, fom.Nh)
+    psi = np.array([np.sin((k + 1) * np.pi * x) * (1.0 + 0.3 * k * x) for k in range(4)]).T
+    psi += 1e-2 * rng.standard_normal(psi.shape)
+    psi[0, :] = psi[-1, :] = 0.0
+    nm = NMDEIM(assemble=_as_dolfin(ref, walk_state_operator(fom)), grid=None,
+                tree_walk_params={"ts": WALK_TS[::2], "num_snapshots": 3}, name="nmdeim")
+    ref.base.Reductor.setup(nm, rnd=np.random.RandomState(0))          # N-MDEIM.setup needs a FEniCS space (nonlinear.py:133-157)
+    nm.rows, nm.cols = nm.get_matrix_topology(mu=WALK_MUS[0], t=1.0, u_n=x)
+    nm.run(u_n=psi, mu_space=[dict(m) for m in WALK_MUS[:3]])
+    key = "nmdeim"
+    data[f"{key}__psi"] = psi
+    data[f"{key}__rows"] = np.array(nm.rows, dtype=np.int64)
+    data[f"{key}__cols"] = np.array(nm.cols, dtype=np.int64)
+    data[f"{key}__basis_fom"] = nm.basis_fom
+    data[f"{key}__sigmas"] = nm.sigmas
+    data[f"{key}__dofs"] = np.array(nm.dofs, dtype=np.int64)
+    data[f"{key}__PT_U"] = nm.PT_U
+    _store_report(data, key, nm, Stage)
+    gaps = np.abs(np.diff(nm.sigmas[: nm.N + 1])) / nm.sigmas[0]
+    data[f"{key}__min_gap"] = np.array(gaps.min())
+    n_cut = 3
+    tr = nm.truncate(n_cut)
+    data[f"{key}__trunc_n"] = np.array(n_cut)
+    data[f"{key}__trunc_name"] = np.array(tr.name)
+    data[f"{key}__trunc_basis_fom"] = tr.basis_fom
+    data[f"{key}__trunc_dofs"] = np.array(tr.dofs, dtype=np.int64)
+    data[f"{key}__trunc_PT_U"] = tr.PT_U
+    data[f"{key}__trunc_final"] = np.array(tr.report[Stage.OFFLINE]["basis-shape-final"])
+    # interpolation with the truncated reductor (nonlinear.py:247-283), FOM form
+    u_probe = psi @ np.array([0.3, -0.2, 0.5, 0.1])
+    data[f"{key}__probe_u"] = u_probe
+    data[f"{key}__trunc_interp_fom"] = tr._interpolate(mu=WALK_MUS[1], t=1.7, u_n=u_probe, which=tr.FOM)
+    data[f"{key}__interp_fom"] = nm._interpolate(mu=WALK_MUS[1], t=1.7, u_n=u_probe, which=nm.FOM)
+
+    # -- RomConstructorNonlinear.build_reduced_basis (two-level POD of FOM solves) + truncate
+    from romtime_amd.testing.mock import MockBurgers
+
+    for key, tolerances, num_basis in (("rb_default", {}, None),
+                                       ("rb_tol", {"tol_time": 1.0 - 1e-12, "tol_mu": 1.0 - 1e-10}, None),
+                                       ("rb_num", {}, 9)):
+        bfom = MockBurgers(domain=dict(L0=1.0, nx=60, T=0.6, nt=24),
+                           Lt=lambda t, **mu: 1.0 - 0.1 * np.sin(mu["omega"] * t), bdf2=True)
+        bfom.setup()
+        mus = [dict(alpha_0=0.05 + 0.03 * i, delta=0.3 + 0.1 * i, omega=9.0 + 1.5 * i) for i in range(3)]
+        ad = RefFomAdapter(ref, bfom)
+        ad.setup = lambda: None
+        ad.update_parametrization = bfom.update_parametrization
+
+        def solve(ad=ad, bfom=bfom):
+            bfom.solve()
+            ad.solutions = bfom.solutions
+            ad.nonlinear_snapshots = bfom.nonlinear_snapshots
+
+        ad.solve = solve
+        rom = ref.rom.RomConstructorNonlinear(fom=ad, grid=None, name="S-ROM")
+        rom.setup(rnd=0)
+        sols = rom.build_reduced_basis(mu_space=[dict(m) for m in mus], num_basis=num_basis, tolerances=tolerances)
+        off = rom.report[Stage.OFFLINE]
+        data[f"{key}__mus"] = np.array([[m["alpha_0"], m["delta"], m["omega"]] for m in mus])
+        data[f"{key}__basis"] = rom.basis
+        data[f"{key}__basis_nonlinear"] = rom.basis_nonlinear
+        data[f"{key}__fom_solution_1"] = sols[1]
+        data[f"{key}__basis_time"] = np.array([off["basis-shape-time"][i] for i in range(3)])
+        data[f"{key}__after_walk"] = np.array(off["basis-shape-after-tree-walk"])
+        data[f"{key}__final"] = np.array(off["basis-shape-final"])
+        data[f"{key}__spectrum_mu"] = np.asarray(off["spectrum-mu"])
+        data[f"{key}__energy_mu"] = np.asarray(off["energy-mu"])
+        data[f"{key}__N_basis_time"] = np.array([off["N-basis-shape-time"][i] for i in range(3)])
+        data[f"{key}__N_after_walk"] = np.array(off["N-basis-shape-after-tree-walk"])
+        data[f"{key}__N_final"] = np.array(off["N-basis-shape-final"])
+        data[f"{key}__N_spectrum_mu"] = np.asarray(off["N-spectrum-mu"])
+        for i in range(3):
+            data[f"{key}__spectrum_time_{i}"] = np.asarray(off["spectrum-time"][i])
+            data[f"{key}__N_spectrum_time_{i}"] = np.asarray(off["N-spectrum-time"][i])
+        tr = rom.truncate(2)
+        data[f"{key}__trunc_basis"] = tr.basis
+        data[f"{key}__trunc_final"] = np.array(tr.report[Stage.OFFLINE]["basis-shape-final"])
+        print(f"  {key}: time {data[f'{key}__basis_time']} -> {int(data[f'{key}__after_walk'])} -> {rom.N};"
+              f" nonlinear -> {rom.basis_nonlinear.shape[1]}")
+    data["versions"] = np.array(repr(_versions()))
+    np.savez_compressed(os.path.join(out, "walks.npz"), **data)
+    print("walks.npz:", len(data), "arrays")
+
+
 def main():
     if not os.path.isdir(REF):
         print("reference not present; nothing to do")
@@ -424,6 +668,7 @@ def main():
     gen_deim(ref, HERE)
     gen_rom(ref, HERE)
     gen_sampler(ref, HERE)
+    gen_walks(ref, HERE)
 
 
 if __name__ == "__main__":

@@ -516,7 +516,8 @@ def check_orth_odd_shapes():
         Q, s, e = orth(R, num=4, normalize=False, passes=passes)
         Qr, sr, er = oracle.orth(R, num=4, normalize=False)
         assert Q.shape == (60, 4) and np.all(np.isfinite(Q)), passes
-        assert_allclose(s, sr, rtol=0, atol=1e-13 * sr[0])
+        assert np.all(np.abs(s - sr) <= 2e-13 * sr[0] + 8 * EPS * sr[0] ** 2 / np.maximum(sr, 1e-300))  # the POD bar
+        assert np.all(s[2:] <= 1e-7 * sr[0])     # exact zeros come back as Gram rounding, sqrt(eps) sigma_1 at most
         for i in range(2):
             assert min(np.linalg.norm(Q[:, i] - Qr[:, i]), np.linalg.norm(Q[:, i] + Qr[:, i])) < 1e-9, (passes, i)
         assert np.all(Q[:, 2:] == 0.0), passes
