@@ -18,6 +18,9 @@ def _ns(name, doc, **values):
 _PROBLEMS = dict(FOM="fom", ROM="rom", SROM="srom", HROM="hrom")
 
 ProblemType = _ns("ProblemType", "which model a quantity belongs to", **_PROBLEMS)
+Errors = _ns("Errors", "keys of the per-parameter error payloads the driver writes (conventions.py:36-44)", **_PROBLEMS,
+             SACRIFICIAL="sacrificial", ESTIMATOR="estimator", AVERAGE_ROM="rom_average",
+             AVERAGE_ESTIMATOR="estimator_average", AVERAGE_SACRIFICIAL="srom_average")
 Stage = _ns("Stage", "phase of the reduction workflow", OFFLINE="offline", VALIDATION="validation", ONLINE="online")
 BDF = _ns("BDF", "time scheme order, as the FOM's BDF_SCHEME attribute spells it", ONE="1", TWO="2")
 EmpiricalInterpolation = _ns("EmpiricalInterpolation", "hyper-reductor kinds", DEIM="DEIM", MDEIM="MDEIM",

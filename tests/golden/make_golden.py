@@ -207,6 +207,20 @@ def mdeim_p1_basis(ref):
     return basis, rows[order], cols[order], fom
 
 
+def greedy_margins(basis, dofs):
+    """(top1 - top2) / top1 of |residual| at every greedy step (0 = exact tie), from the reference's own selection."""
+    m = np.empty(len(dofs))
+    for k in range(len(dofs)):
+        if k == 0:
+            r = basis[:, 0]
+        else:
+            c = np.linalg.solve(basis[dofs[:k], :k], basis[dofs[:k], k])
+            r = basis[:, k] - basis[:, :k] @ c
+        a = np.sort(np.abs(r))[::-1]
+        m[k] = (a[0] - a[1]) / a[0]
+    return m
+
+
 def gen_deim(ref, out):
     rng = np.random.RandomState(20260105)
     DEIM = ref.deim.DiscreteEmpiricalInterpolation
@@ -429,74 +443,10 @@ def gen_sampler(ref, out):
 # (nonlinear.py:49-104,159-212,405-468), RomConstructor.build_reduced_basis / truncate
 # (rom.py:169-198,276-412) on the closed-form P1 FOM of romtime_amd.testing.mock
 # ---------------------------------------------------------------------------
-WALK_MUS = [dict(alpha_0=0.4, beta=2.0, delta=0.3), dict(alpha_0=1.1, beta=5.5, delta=1.2),
-            dict(alpha_0=1.7, beta=8.0, delta=0.7), dict(alpha_0=0.9, beta=3.3, delta=1.8)]
-WALK_TS = np.linspace(0.2, 5.0, 9)
-
-
-def walk_forcing(x, t, **mu):
-    """A forcing with genuinely (mu, t)-dependent shape: the per-mu time bases span different subspaces, so the
-    mu-level spectrum has no exact multiplicities (the separable forcing of tests/test_deim.py gives sigma = sqrt(n_mu)
-    twice, and then any rotation of the basis is an equally valid answer)."""
-    return (np.sin(mu["beta"] * x * (1.0 + 0.2 * mu["delta"] * t)) * np.exp(-0.3 * t)
-            + mu["alpha_0"] * np.cos(3.0 * x + mu["delta"] * t) + 0.5 * mu["delta"] * x * x * t)
-
-
-def walk_solver():
-    from romtime_amd.testing.mock import MockBurgers
-
-    fom = MockBurgers(domain=dict(L0=1.0, nx=60, T=5.0, nt=20), Lt=lambda t, **mu: 1.0 + 0.1 * mu["delta"] * t)
-    fom.forcing_term = walk_forcing
-    fom.setup()
-    return fom
-
-
-def walk_rich_operator(fom):
-    """(mu, t)-dependent combination of the P1 operators (all on the tridiagonal pattern)."""
-
-    def assemble(mu=None, t=None, entries=None):
-        w = np.sin((1.0 + mu["delta"]) * np.pi * fom.x_at(mu, t) * (1.0 + 0.3 * t)) * mu["alpha_0"]
-        parts = [(1.0, fom.assemble_stiffness(mu, t, entries=entries)),
-                 (1.0 + t * mu["beta"], fom.assemble_mass(mu, t, entries=entries)),
-                 (mu["delta"], fom.assemble_convection(mu, t, entries=entries)),
-                 (1.0, fom.assemble_trilinear(mu, t, w, entries=entries))]
-        out = parts[0][1] * parts[0][0]
-        for c, a in parts[1:]:
-            out = out + c * a
-        if entries is not None:                      # Dirichlet rows: the combination would give 1+..., keep 1 / 0
-            for k, (i, j) in enumerate(entries):
-                if i in (0, fom.Nh - 1):
-                    out[k] = 1.0 if i == j else 0.0
-            return out
-        out = out.tolil()
-        for i in (0, fom.Nh - 1):
-            out[i, :] = 0.0
-            out[i, i] = 1.0
-        return out.tocsr()
-
-    return assemble
-
-
-def walk_state_operator(fom):
-    """State-dependent operator with (mu, t) dependence: trilinear(u_n) + nonlinear lifting(mu, t)."""
-
-    def assemble(mu=None, t=None, u_n=None, entries=None):
-        mu2 = dict(mu, omega=1.0 + mu["beta"])
-        a = fom.assemble_trilinear(mu2, t, u_n, entries=entries)
-        b = fom.assemble_nonlinear_lifting(mu2, t, entries=entries)
-        if entries is not None:
-            out = a + b
-            for k, (i, j) in enumerate(entries):
-                if i in (0, fom.Nh - 1):
-                    out[k] = 1.0 if i == j else 0.0
-            return out
-        out = (a + b).tolil()
-        for i in (0, fom.Nh - 1):
-            out[i, :] = 0.0
-            out[i, i] = 1.0
-        return out.tocsr()
-
-    return assemble
+from romtime_amd.testing.walk_inputs import (PISTON_MUS, PISTON_SROM_TRUNCATE, PISTON_TOL_MU, PISTON_TOL_TIME,  # noqa: E402
+                                              PISTON_TS, RB_CASES, RB_MUS,
+                                              WALK_MUS, WALK_TS, nmdeim_states, piston_grid, rb_fom,
+                                              walk_rich_operator, walk_solver, walk_state_operator)
 
 
 def _as_dolfin(ref, fn):
@@ -522,14 +472,19 @@ def _store_report(data, key, red, Stage):
         data[f"{key}__spectrum_time_{i}"] = np.asarray(off["spectrum-time"][i])
 
 
-def _check_well_posed(name, sigmas, kept, thresholds=(1e-7,)):
-    """The fixture must not sit on a knife edge: kept singular values separated, none within 20 % of DROP_TOLERANCE."""
-    s = np.asarray(sigmas)
-    for th in thresholds:
-        assert not np.any((s > 0.8 * th) & (s < 1.25 * th)), (name, "sigma near the drop tolerance", s)
-    k = s[: kept + 1] if kept < len(s) else s[:kept]
-    gaps = np.abs(np.diff(k)) / k[0]
-    return float(gaps.min()) if gaps.size else 1.0
+def _check_well_posed(name, report, tol_time=None, tol_mu=None, prefix=""):
+    """A fixture must not sit on a knife edge of the truncation rules (pod.py:46-57): no singular value within 4 % of
+    DROP_TOLERANCE where the drop branch decides, no energy within 10 % of (1 - tol) of ``tol`` where ``tol`` does."""
+    def check(tag, s, e, tol):
+        s, e = np.asarray(s), np.asarray(e)
+        if tol:
+            assert not np.any(np.abs(e - tol) < 0.1 * (1.0 - tol)), (name, tag, "energy on the tolerance", e, tol)
+        else:
+            assert not np.any((s > 0.96e-7) & (s < 1.04e-7)), (name, tag, "sigma on the drop tolerance", s)
+
+    for i, s in report[prefix + "spectrum-time"].items():
+        check(f"time {i}", s, report[prefix + "energy-time"][i], tol_time)
+    check("mu", report[prefix + "spectrum-mu"], report[prefix + "energy-mu"], tol_mu)
 
 
 def gen_walks(ref, out):
@@ -554,7 +509,9 @@ def gen_walks(ref, out):
         data[f"{key}__dofs"] = np.array([i for (i,) in d.dofs], dtype=np.int64)
         data[f"{key}__PT_U"] = d.PT_U
         _store_report(data, key, d, Stage)
-        data[f"{key}__min_gap"] = np.array(_check_well_posed(key, d.sigmas, d.N))
+        data[f"{key}__margin"] = greedy_margins(d.basis_fom, data[f"{key}__dofs"])
+        if not extra.get("num_mu"):
+            _check_well_posed(key, d.report[Stage.OFFLINE], extra.get("tol_time"), extra.get("tol_mu"))
 
     # -- MDEIM.run: the reference's own acceptance operators (separable -> degenerate spectra) and a rich one
     ops_m = {"mdeim_stiffness": fom.assemble_stiffness, "mdeim_rich": walk_rich_operator(fom)}
@@ -570,15 +527,11 @@ def gen_walks(ref, out):
         data[f"{key}__dofs"] = np.array(md.dofs, dtype=np.int64)
         data[f"{key}__PT_U"] = md.PT_U
         _store_report(data, key, md, Stage)
-        gaps = np.abs(np.diff(md.sigmas[: md.N + 1])) / md.sigmas[0]
-        data[f"{key}__min_gap"] = np.array(gaps.min() if gaps.size else 1.0)
+        _check_well_posed(key, md.report[Stage.OFFLINE])
 
     # -- N-MDEIM.run (three levels, all normalised) + truncate(n)
-    rng = np.random.RandomState(5)
     x = np.linspace(0.0, 1.0, fom.Nh)
-    psi = np.array([np.sin((k + 1) * np.pi * x) * (1.0 + 0.3 * k * x) for k in range(4)]).T
-    psi += 1e-2 * rng.standard_normal(psi.shape)
-    psi[0, :] = psi[-1, :] = 0.0
+    psi = nmdeim_states(fom.Nh)
     nm = NMDEIM(assemble=_as_dolfin(ref, walk_state_operator(fom)), grid=None,
                 tree_walk_params={"ts": WALK_TS[::2], "num_snapshots": 3}, name="nmdeim")
     ref.base.Reductor.setup(nm, rnd=np.random.RandomState(0))          # N-MDEIM.setup needs a FEniCS space (nonlinear.py:133-157)
@@ -593,8 +546,7 @@ def gen_walks(ref, out):
     data[f"{key}__dofs"] = np.array(nm.dofs, dtype=np.int64)
     data[f"{key}__PT_U"] = nm.PT_U
     _store_report(data, key, nm, Stage)
-    gaps = np.abs(np.diff(nm.sigmas[: nm.N + 1])) / nm.sigmas[0]
-    data[f"{key}__min_gap"] = np.array(gaps.min())
+    _check_well_posed(key, nm.report[Stage.OFFLINE])
     n_cut = 3
     tr = nm.truncate(n_cut)
     data[f"{key}__trunc_n"] = np.array(n_cut)
@@ -603,22 +555,17 @@ def gen_walks(ref, out):
     data[f"{key}__trunc_dofs"] = np.array(tr.dofs, dtype=np.int64)
     data[f"{key}__trunc_PT_U"] = tr.PT_U
     data[f"{key}__trunc_final"] = np.array(tr.report[Stage.OFFLINE]["basis-shape-final"])
-    # interpolation with the truncated reductor (nonlinear.py:247-283), FOM form
-    u_probe = psi @ np.array([0.3, -0.2, 0.5, 0.1])
+    # interpolation (nonlinear.py:247-283, FOM form) at a training (mu, t) of a state inside the training span whose
+    # coefficients sum to one (the operator is affine in the state): the interpolant reproduces the operator
+    u_probe = psi @ np.array([0.4, -0.2, 0.6, 0.2])
     data[f"{key}__probe_u"] = u_probe
-    data[f"{key}__trunc_interp_fom"] = tr._interpolate(mu=WALK_MUS[1], t=1.7, u_n=u_probe, which=tr.FOM)
-    data[f"{key}__interp_fom"] = nm._interpolate(mu=WALK_MUS[1], t=1.7, u_n=u_probe, which=nm.FOM)
+    data[f"{key}__probe_t"] = np.array(WALK_TS[2])
+    data[f"{key}__interp_fom"] = nm._interpolate(mu=WALK_MUS[1], t=WALK_TS[2], u_n=u_probe, which=nm.FOM)
 
     # -- RomConstructorNonlinear.build_reduced_basis (two-level POD of FOM solves) + truncate
-    from romtime_amd.testing.mock import MockBurgers
-
-    for key, tolerances, num_basis in (("rb_default", {}, None),
-                                       ("rb_tol", {"tol_time": 1.0 - 1e-12, "tol_mu": 1.0 - 1e-10}, None),
-                                       ("rb_num", {}, 9)):
-        bfom = MockBurgers(domain=dict(L0=1.0, nx=60, T=0.6, nt=24),
-                           Lt=lambda t, **mu: 1.0 - 0.1 * np.sin(mu["omega"] * t), bdf2=True)
-        bfom.setup()
-        mus = [dict(alpha_0=0.05 + 0.03 * i, delta=0.3 + 0.1 * i, omega=9.0 + 1.5 * i) for i in range(3)]
+    for key, tolerances, num_basis in RB_CASES:
+        bfom = rb_fom()
+        mus = RB_MUS
         ad = RefFomAdapter(ref, bfom)
         ad.setup = lambda: None
         ad.update_parametrization = bfom.update_parametrization
@@ -649,6 +596,9 @@ def gen_walks(ref, out):
         for i in range(3):
             data[f"{key}__spectrum_time_{i}"] = np.asarray(off["spectrum-time"][i])
             data[f"{key}__N_spectrum_time_{i}"] = np.asarray(off["N-spectrum-time"][i])
+        if key != "rb_num":
+            _check_well_posed(key, off, tolerances.get("tol_time"), tolerances.get("tol_mu"))
+            _check_well_posed(key + " (nonlinear)", off, tolerances.get("tol_time"), None, prefix="N-")
         tr = rom.truncate(2)
         data[f"{key}__trunc_basis"] = tr.basis
         data[f"{key}__trunc_final"] = np.array(tr.report[Stage.OFFLINE]["basis-shape-final"])
@@ -657,6 +607,193 @@ def gen_walks(ref, out):
     data["versions"] = np.array(repr(_versions()))
     np.savez_compressed(os.path.join(out, "walks.npz"), **data)
     print("walks.npz:", len(data), "arrays")
+
+
+# ---------------------------------------------------------------------------
+# f1: the real caller.  HyperReducedPiston (rom/hrom.py:979-1182) and its base class's run_offline_rom,
+# run_offline_hyperreduction, project_reductors, evaluate_validation / evaluate_online -> _evaluate
+# (rom/hrom.py:308-342, 419-452, 459-626) drive an S-ROM / ROM pair of RomConstructorNonlinear with all six operators
+# hyper-reduced.  Only what needs FEniCS is stepped around: ``setup`` (builds the FEniCS FOM; the duck-typed mock
+# is attached instead) and the two ``N-MDEIM.setup(rnd, V)`` calls inside ``setup_hyperreduction`` (they interpolate
+# an Expression on the FE space to get a topology; the topology is read off the mock with u_n = x).
+# ---------------------------------------------------------------------------
+class PistonFomAdapter(RefFomAdapter):
+    """RefFomAdapter + what the driver itself touches (hrom.py:504-626)."""
+
+    def __init__(self, ref, fom):
+        super().__init__(ref, fom)
+        self.V = None
+
+    def setup(self):
+        pass
+
+    def update_parametrization(self, mu):
+        self._fom.update_parametrization(mu)
+
+    def solve(self):
+        self._fom.solve()
+        self.solutions = self._fom.solutions
+        self.nonlinear_snapshots = self._fom.nonlinear_snapshots
+
+    def _wrap(self, fn, **kw):
+        out = fn(**kw)
+        return out if kw.get("entries") is not None else self._mat(out)
+
+    def assemble_mass(self, mu=None, t=None, entries=None):
+        return self._wrap(self._fom.assemble_mass, mu=mu, t=t, entries=entries)
+
+    def assemble_stiffness(self, mu=None, t=None, entries=None):
+        return self._wrap(self._fom.assemble_stiffness, mu=mu, t=t, entries=entries)
+
+    def assemble_convection(self, mu=None, t=None, entries=None):
+        return self._wrap(self._fom.assemble_convection, mu=mu, t=t, entries=entries)
+
+    def assemble_nonlinear_lifting(self, mu=None, t=None, entries=None):
+        return self._wrap(self._fom.assemble_nonlinear_lifting, mu=mu, t=t, entries=entries)
+
+    def assemble_trilinear(self, mu=None, t=None, u_n=None, entries=None):
+        return self._wrap(self._fom.assemble_trilinear, mu=mu, t=t, u_n=u_n, entries=entries)
+
+    def assemble_lifting(self, mu=None, t=None, entries=None):
+        out = self._fom.assemble_lifting(mu, t, entries=entries)
+        return out if entries is not None else self._ref.Vector(out)
+
+    assemble_rhs = assemble_lifting       # Burgers has no forcing: the right-hand side functional is the lifting term
+
+    def assemble_nonlinear(self, mu=None, t=None, u_n=None, entries=None):
+        raise NotImplementedError         # the NONLINEAR model is switched off (hrom.py:1112-1140 only runs TRILINEAR)
+
+    def compute_mass_conservation(self, mu, ts, solutions, which):
+        """FEniCS quadrature in the reference (fom/nonlinear.py:627-700): reporting only, not on the path."""
+        return {"which": which, "timesteps": list(ts), "mass": [float(np.sum(u)) for u in solutions]}
+
+
+def run_piston_driver(ref, classes=None):
+    """Drive HyperReducedPiston's own methods (the reference's code) over ``classes`` = dict(rom=, deim=, mdeim=,
+    nmdeim=, reductor=): the reference's classes by default (fixture generation), or romtime_amd's - the drop-in
+    check of tests/test_hrom_flow.py, where the names the driver module bound at import are re-pointed first."""
+    import tempfile
+
+    RP, OT, Stage = ref.conv.RomParameters, ref.conv.OperatorType, ref.conv.Stage
+    hrom = ref.hrom
+    if classes is None:
+        classes = dict(rom=ref.rom.RomConstructorNonlinear, deim=ref.deim.DiscreteEmpiricalInterpolation,
+                       mdeim=ref.deim.MatrixDiscreteEmpiricalInterpolation,
+                       nmdeim=ref.nonlinear.MatrixDiscreteEmpiricalInterpolationNonlinear, reductor=ref.base.Reductor,
+                       compute_rom_difference=ref.utils.compute_rom_difference)
+    saved = {k: getattr(hrom, k) for k in ("DiscreteEmpiricalInterpolation", "MatrixDiscreteEmpiricalInterpolation",
+                                           "MatrixDiscreteEmpiricalInterpolationNonlinear", "RomConstructorNonlinear",
+                                           "compute_rom_difference")}
+    hrom.DiscreteEmpiricalInterpolation = classes["deim"]
+    hrom.MatrixDiscreteEmpiricalInterpolation = classes["mdeim"]
+    hrom.MatrixDiscreteEmpiricalInterpolationNonlinear = classes["nmdeim"]
+    hrom.RomConstructorNonlinear = classes["rom"]
+    hrom.compute_rom_difference = classes["compute_rom_difference"]
+    try:
+        grid = piston_grid()
+        rnd = np.random.RandomState(0)
+        walk = {"ts": PISTON_TS, RP.NUM_SNAPSHOTS: None}
+        H = hrom.HyperReducedPiston(
+            grid=grid, fom_params={}, rom_params={RP.NUM_SNAPSHOTS: None, RP.SROM_TRUNCATE: PISTON_SROM_TRUNCATE,
+                                                  RP.TOL_TIME: PISTON_TOL_TIME, RP.TOL_MU: PISTON_TOL_MU},
+            deim_params=dict(walk), mdeim_params=dict(walk), mdeim_nonlinear_params=dict(walk),
+            models={OT.MASS: True, OT.STIFFNESS: True, OT.RHS: True, OT.CONVECTION: True, OT.NONLINEAR_LIFTING: True,
+                    OT.TRILINEAR: True}, rnd=rnd)
+        fom = PistonFomAdapter(ref, rb_fom())
+        # -- HyperReducedPiston.setup (hrom.py:1003-1038) without the FEniCS solver
+        H.fom = fom
+        H.rom = classes["rom"](fom=fom, grid=grid, name="ROM")
+        H.rom.setup(rnd=rnd)
+        H.srom = classes["rom"](fom=fom, grid=grid, name="S-ROM")
+        H.srom.setup(rnd=rnd)
+        # -- setup_hyperreduction (hrom.py:274-306 + 1040-1086): same constructors, same names, same callbacks
+        hrom.HyperReducedOrderModelFixed.setup_hyperreduction(H)          # RHS, Mass, Stiffness: runs unmodified
+        MDEIM, NMDEIM = classes["mdeim"], classes["nmdeim"]
+        H.mdeim_convection = MDEIM(name=OT.CONVECTION, assemble=fom.assemble_convection, grid=grid,
+                                   tree_walk_params=H.mdeim_params)
+        H.mdeim_trilinear_lifting = MDEIM(name=OT.NONLINEAR_LIFTING, assemble=fom.assemble_nonlinear_lifting, grid=grid,
+                                          tree_walk_params=H.mdeim_params)
+        H.mdeim_trilinear = NMDEIM(name=OT.TRILINEAR, assemble=fom.assemble_trilinear, grid=grid,
+                                   tree_walk_params=H.mdeim_nonlinear_params)
+        H.mdeim_convection.setup(rnd=rnd)
+        H.mdeim_trilinear_lifting.setup(rnd=rnd)
+        classes["reductor"].setup(H.mdeim_trilinear, rnd=rnd)
+        x = np.linspace(0.0, 1.0, fom._fom.Nh)
+        H.mdeim_trilinear.rows, H.mdeim_trilinear.cols = H.mdeim_trilinear.get_matrix_topology(mu=PISTON_MUS[0], t=1.0, u_n=x)
+
+        captured = {}
+
+        def capture(rom_obj, label):
+            orig = rom_obj.solve
+
+            def solve(mu, step):
+                idx = orig(mu=mu, step=step)
+                captured[(label, step, idx)] = (rom_obj.solutions.rom.copy(), rom_obj.solutions.fom.copy())
+                return idx
+
+            rom_obj.solve = solve
+
+        here = os.getcwd()
+        with tempfile.TemporaryDirectory() as tmp:
+            os.chdir(tmp)
+            try:
+                mus = [dict(m) for m in PISTON_MUS]
+                H.run_offline_rom(mu_space=mus)                                   # hrom.py:308-342
+                H.run_offline_hyperreduction(mu_space=mus, evaluate=False)        # hrom.py:1088-1140
+                H.project_reductors()                                             # hrom.py:265-272
+                capture(H.rom, "rom")
+                capture(H.srom, "srom")
+                H.evaluate_validation()                                           # hrom.py:476-481 -> _evaluate
+                H.evaluate_online(params={"num": 2}, rnd=np.random.RandomState(1))  # hrom.py:483-502
+                written = sorted(os.listdir(tmp))
+            finally:
+                os.chdir(here)
+    finally:
+        for k, v in saved.items():
+            setattr(hrom, k, v)
+    data = {}
+    data["offline_mus"] = np.array([[m[k] for k in ("a0", "omega", "delta", "alpha_0")] for m in PISTON_MUS])
+    online = H.rom.mu_space[Stage.ONLINE]
+    data["online_mus"] = np.array([[m[k] for k in ("a0", "omega", "delta", "alpha_0")] for m in online])
+    data["online_mach"] = np.array([m["piston_mach"] for m in online])
+    data["N_rom"], data["N_srom"] = np.array(H.rom.N), np.array(H.srom.N)
+    for name, red in (("rhs", H.deim_rhs), ("mass", H.mdeim_mass), ("stiffness", H.mdeim_stiffness),
+                      ("convection", H.mdeim_convection), ("nonlinear_lifting", H.mdeim_trilinear_lifting),
+                      ("trilinear", H.mdeim_trilinear)):
+        data[f"N__{name}"] = np.array(red.N)
+        data[f"dofs__{name}"] = np.array(red.dofs, dtype=np.int64)
+    data["srom_basis"] = H.srom.basis
+    data["srom_basis_nonlinear"] = H.srom.basis_nonlinear
+    off = H.srom.report[Stage.OFFLINE]
+    data["srom_spectrum_mu"] = np.asarray(off["spectrum-mu"])
+    data["srom_N_spectrum_mu"] = np.asarray(off["N-spectrum-mu"])
+    for i in range(3):
+        data[f"srom_spectrum_time_{i}"] = np.asarray(off["spectrum-time"][i])
+        data[f"srom_N_spectrum_time_{i}"] = np.asarray(off["N-spectrum-time"][i])
+        data[f"srom_basis_time_{i}"] = np.array(off["basis-shape-time"][i])
+    for which in (Stage.VALIDATION, Stage.ONLINE):
+        for idx, payload in H.errors[which].items():
+            for kind, arr in payload.items():
+                data[f"errors__{which}__{idx}__{kind}"] = np.asarray(arr)
+            for label in ("rom", "srom"):
+                uN, uh = captured[(label, which, idx)]
+                data[f"{label}_uN__{which}__{idx}"] = uN
+                data[f"{label}_uh__{which}__{idx}"] = uh
+    data["validation_solution_1"] = H.validation_solutions[1]
+    data["files_written"] = np.array(written)
+    return data, H
+
+
+def gen_hrom(ref, out):
+    Stage = ref.conv.Stage
+    data, H = run_piston_driver(ref)
+    data["versions"] = np.array(repr(_versions()))
+    np.savez_compressed(os.path.join(out, "hrom.npz"), **data)
+    print("hrom.npz: N_rom", H.rom.N, "N_srom", H.srom.N, {k[3:]: int(v) for k, v in data.items() if k.startswith("N__")},
+          "online mach", data["online_mach"])
+    for which in (Stage.VALIDATION, Stage.ONLINE):
+        for idx, payload in H.errors[which].items():
+            print("  ", which, idx, {k: float(np.max(v)) for k, v in payload.items()})
 
 
 def main():
@@ -669,6 +806,7 @@ def main():
     gen_rom(ref, HERE)
     gen_sampler(ref, HERE)
     gen_walks(ref, HERE)
+    gen_hrom(ref, HERE)
 
 
 if __name__ == "__main__":
