@@ -149,3 +149,25 @@ def dump_pickle(path, obj):
 
     with open(path, mode="wb") as fp:
         pickle.dump(obj, fp)
+
+
+def dump_json(path, obj):
+    """``mu_space.json`` / ``setup.json`` writer (utils.py:214-218; ujson there, the same wire format)."""
+    import json
+
+    with open(path, mode="w") as fp:
+        json.dump(obj, fp)
+
+
+def read_json(path):
+    import json
+
+    with open(path, mode="r") as fp:
+        return json.load(fp)
+
+
+def dump_csv(path, obj):
+    """Tabular report writer of the drivers (utils.py:228-233)."""
+    import pandas as pd
+
+    pd.DataFrame(obj).to_csv(path)

@@ -690,37 +690,42 @@ def run_piston_driver(ref, classes=None):
     hrom.RomConstructorNonlinear = classes["rom"]
     hrom.compute_rom_difference = classes["compute_rom_difference"]
     try:
-        grid = piston_grid()
-        rnd = np.random.RandomState(0)
-        walk = {"ts": PISTON_TS, RP.NUM_SNAPSHOTS: None}
-        H = hrom.HyperReducedPiston(
-            grid=grid, fom_params={}, rom_params={RP.NUM_SNAPSHOTS: None, RP.SROM_TRUNCATE: PISTON_SROM_TRUNCATE,
-                                                  RP.TOL_TIME: PISTON_TOL_TIME, RP.TOL_MU: PISTON_TOL_MU},
-            deim_params=dict(walk), mdeim_params=dict(walk), mdeim_nonlinear_params=dict(walk),
-            models={OT.MASS: True, OT.STIFFNESS: True, OT.RHS: True, OT.CONVECTION: True, OT.NONLINEAR_LIFTING: True,
-                    OT.TRILINEAR: True}, rnd=rnd)
-        fom = PistonFomAdapter(ref, rb_fom())
-        # -- HyperReducedPiston.setup (hrom.py:1003-1038) without the FEniCS solver
-        H.fom = fom
-        H.rom = classes["rom"](fom=fom, grid=grid, name="ROM")
-        H.rom.setup(rnd=rnd)
-        H.srom = classes["rom"](fom=fom, grid=grid, name="S-ROM")
-        H.srom.setup(rnd=rnd)
-        # -- setup_hyperreduction (hrom.py:274-306 + 1040-1086): same constructors, same names, same callbacks
-        hrom.HyperReducedOrderModelFixed.setup_hyperreduction(H)          # RHS, Mass, Stiffness: runs unmodified
-        MDEIM, NMDEIM = classes["mdeim"], classes["nmdeim"]
-        H.mdeim_convection = MDEIM(name=OT.CONVECTION, assemble=fom.assemble_convection, grid=grid,
-                                   tree_walk_params=H.mdeim_params)
-        H.mdeim_trilinear_lifting = MDEIM(name=OT.NONLINEAR_LIFTING, assemble=fom.assemble_nonlinear_lifting, grid=grid,
-                                          tree_walk_params=H.mdeim_params)
-        H.mdeim_trilinear = NMDEIM(name=OT.TRILINEAR, assemble=fom.assemble_trilinear, grid=grid,
-                                   tree_walk_params=H.mdeim_nonlinear_params)
-        H.mdeim_convection.setup(rnd=rnd)
-        H.mdeim_trilinear_lifting.setup(rnd=rnd)
-        classes["reductor"].setup(H.mdeim_trilinear, rnd=rnd)
-        x = np.linspace(0.0, 1.0, fom._fom.Nh)
-        H.mdeim_trilinear.rows, H.mdeim_trilinear.cols = H.mdeim_trilinear.get_matrix_topology(mu=PISTON_MUS[0], t=1.0, u_n=x)
+        def make_driver():
+            grid = piston_grid()
+            rnd = np.random.RandomState(0)
+            walk = {"ts": PISTON_TS, RP.NUM_SNAPSHOTS: None}
+            H = hrom.HyperReducedPiston(
+                grid=grid, fom_params={}, rom_params={RP.NUM_SNAPSHOTS: None, RP.SROM_TRUNCATE: PISTON_SROM_TRUNCATE,
+                                                      RP.TOL_TIME: PISTON_TOL_TIME, RP.TOL_MU: PISTON_TOL_MU,
+                                                      RP.SROM_KEEP: None, RP.NMDEIM_SIZE: None},
+                deim_params=dict(walk), mdeim_params=dict(walk), mdeim_nonlinear_params=dict(walk),
+                models={OT.MASS: True, OT.STIFFNESS: True, OT.RHS: True, OT.CONVECTION: True, OT.NONLINEAR_LIFTING: True,
+                        OT.TRILINEAR: True}, rnd=rnd)
+            fom = PistonFomAdapter(ref, rb_fom())
+            # -- HyperReducedPiston.setup (hrom.py:1003-1038) without the FEniCS solver
+            H.fom = fom
+            H.rom = classes["rom"](fom=fom, grid=grid, name="ROM")
+            H.rom.setup(rnd=rnd)
+            H.srom = classes["rom"](fom=fom, grid=grid, name="S-ROM")
+            H.srom.setup(rnd=rnd)
+            # -- setup_hyperreduction (hrom.py:274-306 + 1040-1086): same constructors, same names, same callbacks
+            hrom.HyperReducedOrderModelFixed.setup_hyperreduction(H)          # RHS, Mass, Stiffness: runs unmodified
+            MDEIM, NMDEIM = classes["mdeim"], classes["nmdeim"]
+            H.mdeim_convection = MDEIM(name=OT.CONVECTION, assemble=fom.assemble_convection, grid=grid,
+                                       tree_walk_params=H.mdeim_params)
+            H.mdeim_trilinear_lifting = MDEIM(name=OT.NONLINEAR_LIFTING, assemble=fom.assemble_nonlinear_lifting, grid=grid,
+                                              tree_walk_params=H.mdeim_params)
+            H.mdeim_trilinear = NMDEIM(name=OT.TRILINEAR, assemble=fom.assemble_trilinear, grid=grid,
+                                       tree_walk_params=H.mdeim_nonlinear_params)
+            H.mdeim_convection.setup(rnd=rnd)
+            H.mdeim_trilinear_lifting.setup(rnd=rnd)
+            classes["reductor"].setup(H.mdeim_trilinear, rnd=rnd)
+            x = np.linspace(0.0, 1.0, fom._fom.Nh)
+            H.mdeim_trilinear.rows, H.mdeim_trilinear.cols = H.mdeim_trilinear.get_matrix_topology(mu=PISTON_MUS[0], t=1.0,
+                                                                                                 u_n=x)
+            return H
 
+        H = make_driver()
         captured = {}
 
         def capture(rom_obj, label):
@@ -745,7 +750,16 @@ def run_piston_driver(ref, classes=None):
                 capture(H.srom, "srom")
                 H.evaluate_validation()                                           # hrom.py:476-481 -> _evaluate
                 H.evaluate_online(params={"num": 2}, rnd=np.random.RandomState(1))  # hrom.py:483-502
+                # -- f2: leave the artefacts behind and resume from them in a fresh driver (hrom.py:137-177, 344-417)
+                H.dump_mu_space()
+                H.dump_reduced_basis()
+                H.dump_nonlinear_basis()
+                H.dump_validation_fom()
                 written = sorted(os.listdir(tmp))
+                H2 = make_driver()
+                H2.start_from_existing_basis()
+                H2.project_reductors()
+                H2.evaluate_validation()
             finally:
                 os.chdir(here)
     finally:
@@ -762,6 +776,10 @@ def run_piston_driver(ref, classes=None):
                       ("trilinear", H.mdeim_trilinear)):
         data[f"N__{name}"] = np.array(red.N)
         data[f"dofs__{name}"] = np.array(red.dofs, dtype=np.int64)
+        # equal singular values among the kept modes: the basis columns (hence the entries) are LAPACK's arbitrary pick
+        sig = np.asarray(red.sigmas if red.sigmas is not None else H.srom.report[Stage.OFFLINE]["N-spectrum-mu"])
+        kept = sig[: red.N + 1] if red.N < len(sig) else sig[: red.N]
+        data[f"cluster__{name}"] = np.array(bool(np.any(np.abs(np.diff(kept)) < 1e-6 * sig[0])))
     data["srom_basis"] = H.srom.basis
     data["srom_basis_nonlinear"] = H.srom.basis_nonlinear
     off = H.srom.report[Stage.OFFLINE]
@@ -781,6 +799,11 @@ def run_piston_driver(ref, classes=None):
                 data[f"{label}_uh__{which}__{idx}"] = uh
     data["validation_solution_1"] = H.validation_solutions[1]
     data["files_written"] = np.array(written)
+    data["resume_N_rom"], data["resume_N_srom"] = np.array(H2.rom.N), np.array(H2.srom.N)
+    data["resume_offline_mus"] = np.array([[m[k] for k in ("a0", "omega", "delta", "alpha_0")] for m in H2.rom.mu_space[Stage.OFFLINE]])
+    for idx, payload in H2.errors[Stage.VALIDATION].items():
+        for kind, arr in payload.items():
+            data[f"resume_errors__{idx}__{kind}"] = np.asarray(arr)
     return data, H
 
 
