@@ -520,7 +520,7 @@ def check_orth_odd_shapes():
         assert np.all(s[2:] <= 1e-7 * sr[0])     # exact zeros come back as Gram rounding, sqrt(eps) sigma_1 at most
         for i in range(2):
             assert min(np.linalg.norm(Q[:, i] - Qr[:, i]), np.linalg.norm(Q[:, i] + Qr[:, i])) < 1e-9, (passes, i)
-        assert np.all(Q[:, 2:] == 0.0), passes
+        assert np.abs(Q[:, 2:]).max() < 1e-12, passes     # zero columns (rounding residue divided by a noise sigma at most)
     if torch.cuda.is_available():
         Xd = torch.from_numpy(rng.standard_normal((500, 8))).cuda()
         Qd, s, e = orth(Xd, num=3)
