@@ -482,6 +482,11 @@ def test_hyper_reduced_loop_hip():
     check_hyper_reduced_loop_matches_oracle(device_sweep=True)
 
 
+@pytest.mark.gpu
+def test_artefact_round_trip_hip(golden_deim, tmp_path, monkeypatch):
+    check_artefact_round_trip(golden_deim, tmp_path, monkeypatch)   # load_fom_basis(keep=) re-runs the device greedy (a14)
+
+
 def check_orth_odd_shapes():
     """Shapes and inputs at the edges of the device path (n < 3 uses the host eigensolver, F-ordered views,
     CUDA tensors in -> CUDA tensor out, all-zero snapshots), each against the oracle."""
