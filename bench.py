@@ -16,6 +16,12 @@ Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` for
 kernel (the Gram MFMA kernel, timed with HIP events on its own stream inside the timed region)
 and `cpu_baseline` (the NumPy/SciPy oracle -- the reference's exact library calls -- on a bounded
 row sample, rank 0, N = 1 only).
+
+The metric has a second half, "reduced timesteps/s" (BASELINE.json configs[4]: 1e4 timesteps x 32 parameter
+points, r = 80; single GPU by the north star).  At N = 1 the same process therefore also runs, after the POD
+region, the online sweep of that configuration twice - the direct path (V^T(A V) on the matrix cores every step,
+N_h = 1e5) and the hyper-reduced path ((M)DEIM expansions, nothing of size N_h) - and reports both under
+`secondary`, each with its own `roofline` / `cpu_baseline` (--no-secondary skips it).
 """
 import argparse
 import json
@@ -84,6 +90,99 @@ def cpu_baseline(n, r, sample_rows):
                        f"{dt:.2f} s, numpy {np.__version__}")
 
 
+def secondary_online_sweep(ctx, device, nt, n_mu, r, n_h, with_cpu):
+    """BASELINE.json configs[4]: nt BDF2 steps x n_mu parameter points, r reduced DoFs.  One "step" = one time step of
+    all n_mu reduced systems; value = nt * n_mu / wall with every table resident in HBM."""
+    from romtime_amd import ops
+    from romtime_amd.sweep import hrom_bdf_sweep, rom_bdf_sweep
+    from romtime_amd.testing.workloads import c5_hyper_reduced
+
+    terms, d, V, mus = c5_hyper_reduced(N=n_h, r=r, n_mu=n_mu, nt=nt)
+    nnz = int(d["mass"].size)
+    Vd = ops.to_device(V)
+    dev = lambda a: ops.to_device(np.ascontiguousarray(a))
+    direct_args = [Vd, d["indptr"], d["indices"], dev(d["mass"]), dev(d["terms"]), dev(d["term_coef"]), dev(d["tril"]),
+                   dev(d["rhs_terms"]), dev(d["rhs_coef"]), d["dt"]]
+    up = lambda term: dict(term, F=dev(term["F"]))
+    h_args = (up(terms["mass"]), [up(t) for t in terms["lin"]], terms["nl"], [up(t) for t in terms["rhs"]], terms["dt"])
+
+    def timed(fn):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        out = fn()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, out
+
+    short = list(direct_args)
+    short[5], short[8] = direct_args[5][:50], direct_args[8][:50]      # the (step, mu) coefficient tables
+    rom_bdf_sweep(*short, bdf2=True)                                   # warm-up: arenas sized, kernels loaded
+    wall_direct, uN_direct = timed(lambda: rom_bdf_sweep(*direct_args, bdf2=True))
+    stats_direct = ctx.sweep_stats()
+    hrom_bdf_sweep(*h_args, bdf2=True)
+    wall_h, uN_h = timed(lambda: hrom_bdf_sweep(*h_args, bdf2=True))
+    stats_h = ctx.sweep_stats()
+    agree = float((uN_h - uN_direct).norm() / uN_direct.norm())       # the expansions represent the same model exactly
+    # dominant kernel of the direct path, launched as the sweep launches it (n_mu value vectors on the pattern),
+    # bracketed by the ctx's HIP event pair on its own stream
+    ip, ix = ops.to_device_index(d["indptr"]), ops.to_device_index(d["indices"])
+    kv = (direct_args[3][:, None] + 1e-4 * torch.randn((nnz, n_mu), dtype=torch.float64, device=device)).T.contiguous().T
+    ctx.set_profile(True)
+    ks = []
+    for _ in range(12):
+        ops.project_csr_batched(ip, ix, kv, Vd)
+        ks.append(ctx.last_gemm_ms())
+    ctx.set_profile(False)
+    k_ms = float(np.mean(ks[2:]))
+    flops = n_mu * (2.0 * nnz * r + 2.0 * n_h * r * r)
+    alg_bytes = 8.0 * (n_mu * nnz + n_h * r)
+    achieved = flops / (k_ms * 1e-3) / 1e12
+    out = {
+        "metric": "reduced timesteps/s",
+        "config": {"workload": f"online_sweep_{nt}steps_x_{n_mu}mu_r{r}_bdf2", "n_h_direct_path": n_h, "nnz": nnz,
+                   "interpolation_coefficients": int(sum(t["F"].shape[2] for t in [terms["mass"]] + terms["lin"])
+                                                     + terms["nl"]["W"].shape[0])},
+        "direct": {"value": nt * n_mu / wall_direct, "unit": "reduced timesteps/s", "wall_s": wall_direct,
+                   "ms_per_step_all_mu": 1e3 * wall_direct / nt, "solves": stats_direct},
+        "hyper_reduced": {"value": nt * n_mu / wall_h, "unit": "reduced timesteps/s", "wall_s": wall_h,
+                          "ms_per_step_all_mu": 1e3 * wall_h / nt, "solves": stats_h,
+                          "rel_l2_vs_direct_path": agree, "bound": "latency (4 dependent launches per step)"},
+        "roofline": dict(bound="mfma", achieved=achieved, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
+                         frac=achieved / FP64_MFMA_PEAK_TFLOPS, traffic=None,
+                         kernel="project_fused_kernel<5> (V^T(A_b V) for the n_mu operators of one step)", kernel_ms=k_ms,
+                         algorithmic_flops=flops, algorithmic_bytes=alg_bytes,
+                         whole_step_frac=(nt * flops / wall_direct / 1e12) / FP64_MFMA_PEAK_TFLOPS),
+    }
+    if with_cpu:
+        from oracle import romtime_oracle as oracle
+        from romtime_amd.testing.mock import AffineBurgers
+        from threadpoolctl import threadpool_limits
+
+        cores = min(16, len(os.sched_getaffinity(0)))
+        with threadpool_limits(limits=cores):
+            n_direct = 8
+            small = AffineBurgers(N=n_h, nt=n_direct, dt=d["dt"], bdf2=True, seed=5)
+            t0 = time.perf_counter()
+            ref, _ = oracle.rom_solve_nonlinear(small, V, mus[0], solver=oracle.reduced_solve)   # GMRES as the reference
+            cpu_direct = (time.perf_counter() - t0) / n_direct
+            err_direct = float(np.linalg.norm(uN_direct[0, :n_direct].cpu().numpy().T - ref) / np.linalg.norm(ref))
+            n_h_steps = 2000
+            cut = lambda term: dict(term, F=term["F"][:n_h_steps])
+            t0 = time.perf_counter()
+            href = oracle.hrom_solve(cut(terms["mass"]), [cut(t) for t in terms["lin"]], terms["nl"],
+                                     [cut(t) for t in terms["rhs"]], 0, r, n_h_steps, d["dt"], True)
+            cpu_h = (time.perf_counter() - t0) / n_h_steps
+            err_h = float(np.linalg.norm(uN_h[0, :n_h_steps].cpu().numpy().T - href) / np.linalg.norm(href))
+        out["cpu_baseline"] = {
+            "direct": dict(value=1.0 / cpu_direct, unit="reduced timesteps/s", cores=cores, kind="port",
+                           sample=f"oracle.rom_solve_nonlinear (5 csr.dot + matmul projections + GMRES per step, rom.py:877-929) "
+                                  f"for 1 mu x {n_direct} steps of the workload", rel_l2_device_vs_oracle=err_direct),
+            "hyper_reduced": dict(value=1.0 / cpu_h, unit="reduced timesteps/s", cores=cores, kind="port",
+                                  sample=f"oracle.hrom_solve (theta solves + dense solve per step, deim.py:416-452) for 1 mu x "
+                                         f"{n_h_steps} steps of the workload", rel_l2_device_vs_oracle=err_h),
+        }
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +193,8 @@ def main():
     ap.add_argument("--modes", type=int, default=R_MODES)
     ap.add_argument("--cpu-sample-rows", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the online-sweep half of the metric (N = 1 only)")
+    ap.add_argument("--sweep-steps", type=int, default=10_000)
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -170,12 +271,16 @@ def main():
         alg_flops = n_local * n * (n + 1)           # symmetric Gram: N n (n+1) flops
         alg_bytes = 8 * (n_local * n + n * n)       # read X once + write G
         achieved = alg_flops / (k_ms * 1e-3) / 1e12
-        traffic = None  # HBM bytes per Gram from the committed PMC passes of this same command (profiles/)
+        # HBM bytes per Gram: NOT measured in this run - PMC counters need rocprofv3's own passes over this same
+        # command; the committed summary of those passes is read and labelled as such
+        traffic, traffic_source = None, None
         tfile = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "gram_traffic.json")
         if world == 1 and (n_h, n) == (N_H, N_S) and os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get("hbm_bytes_per_gram")
+            tj = json.load(open(tfile))
+            traffic = tj.get("hbm_bytes_per_gram")
+            traffic_source = f"static: profiles/gram_traffic.json ({tj.get('source', 'rocprofv3 --pmc passes of `python3 bench.py`')})"
         roofline = dict(bound="mfma", achieved=achieved, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=achieved / FP64_MFMA_PEAK_TFLOPS, traffic=traffic,
+                        frac=achieved / FP64_MFMA_PEAK_TFLOPS, traffic=traffic, traffic_source=traffic_source,
                         kernel="gram128_kernel<KC,false> + gram128_kernel<KC,true> (off-diagonal + diagonal tiles "
                                "of one Gram, one event pair around both launches)", kernel_ms=k_ms,
                         algorithmic_flops=alg_flops, algorithmic_bytes=alg_bytes,
@@ -201,6 +306,11 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, r, min(args.cpu_sample_rows, n_h))
+        if world == 1 and not args.no_secondary:
+            del X, out
+            torch.cuda.empty_cache()
+            line["secondary"] = secondary_online_sweep(ctx, device, nt=args.sweep_steps, n_mu=32, r=80, n_h=100_000,
+                                                       with_cpu=not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist
