@@ -58,6 +58,15 @@ int rt_ctx_set_profile(rt_ctx* ctx, int on);
  * device counter) and replays it for steps 1 .. nt-1 instead of launching four kernels per step; for hosts that
  * cannot keep ahead of the device.  The call then returns only when the sweep has finished. */
 int rt_ctx_set_option(rt_ctx* ctx, const char* name, int value);
+/* "cu_limit" (default 0 = the device's CU count; a multiple of 8): the number of CUs this ctx sizes its persistent grids
+ * for - set it on a ctx whose stream is CU-masked (below) so that, e.g., the snapshot Gram kernel launches exactly the
+ * workgroups its share of the chip holds. */
+
+/* CU-partitioned streams (throughput mode of the POD: the n x n eigensolve of one snapshot set runs beside the Gram
+ * kernel of the next on disjoint CUs).  Creates a HIP stream whose kernels run only on CUs [first, first + count) of
+ * EVERY XCD (MI355X: 32 CUs per XCD; a mask must leave no XCD empty).  *stream is a hipStream_t for rt_ctx_set_stream. */
+int rt_stream_create_cu_range(int device, int first_cu_per_xcd, int n_cu_per_xcd, void** stream);
+int rt_stream_destroy(void* stream);
 int rt_last_gemm_ms(rt_ctx* ctx, double* ms);
 /* Event counters kept on the device by the kernels themselves (nothing on the hot path waits for them); reading one
  * synchronises the ctx stream.  Names: "eig_timeouts" (hand-offs of the small eigensolver that hit their wall-clock

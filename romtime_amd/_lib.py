@@ -35,6 +35,8 @@ SIGNATURES = {
     "rt_last_gemm_ms": (_int, [_p, C.POINTER(C.c_double)]),
     "rt_last_gram_ms": (_int, [_p, C.POINTER(C.c_double)]),
     "rt_ctx_get_counter": (_int, [_p, C.c_char_p, C.POINTER(_i64)]),
+    "rt_stream_create_cu_range": (_int, [_int, _int, _int, C.POINTER(_p)]),
+    "rt_stream_destroy": (_int, [_p]),
     "rt_last_sweep_stats": (_int, [_p, C.POINTER(_i64)]),
     "rt_gram": (_int, [_p, _p, _i64, _i64, _i64, _int, _p]),
     "rt_gram_scale": (_int, [_p, _p, _i64, _p, _int, _p]),
@@ -137,6 +139,10 @@ class Context:
         import torch
 
         dev = torch.cuda.current_device() if torch.cuda.is_available() else 0
+        pinned = getattr(cls._tls, "pinned", None)
+        if pinned is not None:   # inside Context.use(): a pipeline stage with its own ctx (own arenas) on its own stream
+            pinned.lib.rt_ctx_set_stream(pinned.handle, _p(torch.cuda.current_stream().cuda_stream))
+            return pinned
         cache = getattr(cls._tls, "cache", None)
         if cache is None:
             cache = cls._tls.cache = {}
@@ -145,6 +151,25 @@ class Context:
             ctx = cache[dev] = cls(dev)
         ctx.lib.rt_ctx_set_stream(ctx.handle, _p(torch.cuda.current_stream().cuda_stream))
         return ctx
+
+    def use(self, stream):
+        """``with ctx.use(stream):`` - the operators called inside run on ``stream`` (a torch stream) through THIS ctx
+        instead of the thread's default one: concurrent pipeline stages must not share scratch arenas."""
+        import contextlib
+
+        import torch
+
+        @contextlib.contextmanager
+        def scope():
+            prev = getattr(Context._tls, "pinned", None)
+            Context._tls.pinned = self
+            try:
+                with torch.cuda.stream(stream):
+                    yield self
+            finally:
+                Context._tls.pinned = prev
+
+        return scope()
 
     def check(self, rc: int, what: str) -> int:
         if rc < 0:

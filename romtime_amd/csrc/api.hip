@@ -177,7 +177,7 @@ int rt_ctx_create(rt_ctx** out, int device) {
   if (!ctx) return RT_ERR_HIP;
   ctx->device = device;
   hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = prop.multiProcessorCount;
+  if (hipGetDeviceProperties(&prop, device) == hipSuccess) ctx->num_cus = ctx->device_cus = prop.multiProcessorCount;
   if (hipMalloc(reinterpret_cast<void**>(&ctx->dev_counters), sizeof(long) * RT_N_COUNTERS) != hipSuccess ||
       hipMemset(ctx->dev_counters, 0, sizeof(long) * RT_N_COUNTERS) != hipSuccess) {
     delete ctx;
@@ -207,6 +207,35 @@ int rt_ctx_set_stream(rt_ctx* ctx, void* hip_stream) {
   return RT_OK;
 }
 
+// CU-partitioned streams.  On MI355X bit i of a queue's CU mask is CU i / 8 of XCD i % 8, and a mask that leaves an XCD
+// without CUs is ignored (measured: tools/probes/probe_cumask.hip), so a partition gives every XCD's CUs
+// [first, first + count) to one stream and the rest to another: kernels of the two then run side by side on disjoint
+// CUs whatever their launch order (no co-residency assumptions, no spinning on placement).
+int rt_stream_create_cu_range(int device, int first_cu_per_xcd, int n_cu_per_xcd, void** stream) {
+  if (!stream) return RT_ERR_ARG;
+  *stream = nullptr;
+  hipDeviceProp_t prop;
+  if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) return RT_ERR_HIP;
+  const int per_xcd = prop.multiProcessorCount / 8;
+  if (first_cu_per_xcd < 0 || n_cu_per_xcd < 1 || first_cu_per_xcd + n_cu_per_xcd > per_xcd) return RT_ERR_ARG;
+  const int words = (prop.multiProcessorCount + 31) / 32;
+  std::vector<uint32_t> mask((size_t)words, 0u);
+  for (int cu = first_cu_per_xcd; cu < first_cu_per_xcd + n_cu_per_xcd; ++cu)
+    for (int xcd = 0; xcd < 8; ++xcd) {
+      const int bit = cu * 8 + xcd;
+      mask[bit >> 5] |= 1u << (bit & 31);
+    }
+  hipStream_t st = nullptr;
+  if (hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask.data()) != hipSuccess) return RT_ERR_HIP;
+  *stream = st;
+  return RT_OK;
+}
+
+int rt_stream_destroy(void* stream) {
+  if (!stream) return RT_ERR_ARG;
+  return hipStreamDestroy(static_cast<hipStream_t>(stream)) == hipSuccess ? RT_OK : RT_ERR_HIP;
+}
+
 int rt_ctx_synchronize(rt_ctx* ctx) {
   if (!ctx) return RT_ERR_ARG;
   RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
@@ -232,6 +261,14 @@ int rt_ctx_set_option(rt_ctx* ctx, const char* name, int value) {
   }
   if (key == "sweep_graph") {
     ctx->sweep_graph = value != 0;
+    return RT_OK;
+  }
+  if (key == "cu_limit") {  // 0 = the whole device
+    if (value < 0 || value > ctx->device_cus || (value % 8) != 0) {
+      ctx->err = "rt_ctx_set_option: cu_limit must be a multiple of 8 between 0 and the device's CU count";
+      return RT_ERR_ARG;
+    }
+    ctx->num_cus = value ? value : ctx->device_cus;
     return RT_OK;
   }
   ctx->err = "rt_ctx_set_option: unknown option " + key;

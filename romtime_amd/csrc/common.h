@@ -16,7 +16,8 @@ struct rt_ctx {
   size_t scratch_bytes = 0;
   void* scratch2 = nullptr;  // composite arena: workspaces of ops that call the GEMM (AV, DEIM state)
   size_t scratch2_bytes = 0;
-  int num_cus = 256;
+  int num_cus = 256;      // CUs this ctx sizes its grids for: the device's, or fewer when its stream is CU-masked ("cu_limit")
+  int device_cus = 256;
   std::string err;
   int64_t last_grid = 0, last_splits = 0, last_tile = 0;
   bool profile = false;             // bracket the main GEMM kernel with events (rt_ctx_set_profile)

@@ -1,0 +1,182 @@
+"""Throughput mode of the POD for SEQUENCES of independent snapshot sets (the per-parameter time-level PODs of a tree
+walk, rom.py:317-366 / deim.py:330-338; the steps of bench.py): the CUs of the MI355X are split between two streams
+and the stages of consecutive PODs run side by side.
+
+Why.  One POD is a chain  Gram (FP64 matrix cores, all CUs) -> n x n eigensolve (latency-bound: 32 cooperating
+workgroups, most of the chip idle for ~2 ms at n = 512) -> back-projection (HBM-bound).  Nothing inside ONE chain can
+overlap, but the Gram of the NEXT snapshot set needs nothing from this one.
+
+How.  ``hipExtStreamCreateWithCUMask`` through ``rt_stream_create_cu_range``: stream E owns CUs [0, e) of every XCD,
+stream G the other 32 - e (a queue's mask must leave no XCD empty, so a partition is symmetric over the XCDs;
+tools/probes/probe_cumask.hip).  Kernels of the two streams occupy disjoint CUs, so they overlap whatever their launch
+order, and the persistent Gram grid is sized for its share ("cu_limit").  Each stream has its own rt_ctx (own scratch
+arenas).  Per snapshot set i:
+
+    G:  Gram_i                               (record g_i)
+    E:  wait g_i;  scale, tridiagonalise, eigenvalues, k eigenvectors, D^-1 W S^-1      (record e_i)
+    G:  Gram_{i+1};  wait e_i;  Q_i = X_i (D^-1 W S^-1)                                  (record b_i)
+
+so stream G runs  Gram_{i+1} | back-projection_i | Gram_{i+2} ...  without gaps while stream E works one set behind.
+The host only enqueues; it reads the eigenvalues of set i (for sigma, the energy curve and the same acceptance checks
+``pod_device`` applies) when it hands the result out, ``depth`` sets later.  A set that fails a check (deep spectrum,
+clustered eigenvalues, hand-off timeout) is recomputed by ``pod.pod_device`` - the regular, latency-mode route.
+
+Only ``num`` truncation can be enqueued ahead (the number of modes is known before the spectrum, pod.py:51-53);
+``tol`` / default truncation take the regular route."""
+from __future__ import annotations
+
+import collections
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, ops, pod
+
+_p = C.c_void_p
+
+
+class PodPipeline:
+    def __init__(self, eig_cus_per_xcd: int = 4, device=None, backproject_on: str = "gram"):
+        if not torch.cuda.is_available():
+            raise _lib.RomtimeHipError("no MI355X visible: romtime_amd's hot path runs on the GPU only")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        dev = self.device.index
+        lib = _lib.load()
+        self.lib = lib
+        per_xcd = torch.cuda.get_device_properties(dev).multi_processor_count // 8
+        e = int(eig_cus_per_xcd)
+        if not (1 <= e < per_xcd):
+            raise ValueError(f"eig_cus_per_xcd must be in [1, {per_xcd})")
+        self._raw = []
+        hE, hG = _p(), _p()
+        for h, first, count in ((hE, 0, e), (hG, e, per_xcd - e)):
+            rc = lib.rt_stream_create_cu_range(dev, first, count, C.byref(h))
+            if rc != 0:
+                raise _lib.RomtimeHipError(f"rt_stream_create_cu_range failed ({rc})")
+            self._raw.append(h)
+        self.sE = torch.cuda.ExternalStream(hE.value, device=self.device)
+        self.sG = torch.cuda.ExternalStream(hG.value, device=self.device)
+        self.ctxE, self.ctxG = _lib.Context(dev), _lib.Context(dev)
+        self.ctxE.set_option("cu_limit", 8 * e)
+        self.ctxE.set_option("eig_one_xcd", 0)       # the E CUs span all XCDs: write-through hand-off
+        self.ctxG.set_option("cu_limit", 8 * (per_xcd - e))
+        self.backproject_on = backproject_on
+        self.eig_cus = 8 * e
+        self.recomputed = 0                          # sets that failed a check and took the regular route
+        self.last_stage_ms = {}
+
+    def close(self):
+        torch.cuda.synchronize(self.device)
+        for h in self._raw:
+            self.lib.rt_stream_destroy(h)
+        self._raw = []
+
+    def __del__(self):
+        try:
+            if self._raw:
+                self.close()
+        except Exception:
+            pass
+
+    # ---- stages ----------------------------------------------------------------------------------------------
+    def _gram(self, item):
+        X = item["X"]
+        n = X.shape[1]
+        with self.ctxG.use(self.sG):
+            item["t0"] = torch.cuda.Event(enable_timing=True)
+            item["t0"].record()
+            item["G"] = ops.gram(X, out=torch.empty((n, n), dtype=torch.float64, device=X.device))
+            item["g"] = torch.cuda.Event(enable_timing=True)
+            item["g"].record()
+
+    def _eig(self, item):
+        k, normalize = item["k"], item["normalize"]
+        with self.ctxE.use(self.sE):
+            self.sE.wait_event(item["g"])
+            G = item["G"]
+            colnorm, flag = ops.gram_scale(G, normalize)
+            lam_d, status = ops.sym_eig_values(G)
+            Z = ops.sym_eig_vectors(lam_d, k)
+            sig = lam_d[:k].clamp_min(0.0).sqrt()
+            inv = torch.where(sig > 0, 1.0 / sig, torch.zeros_like(sig))
+            item["Zs"] = ((Z / colnorm[:, None] if normalize else Z) * inv[None, :]).contiguous()
+            item["colnorm"], item["Z"] = colnorm, Z
+            head = torch.cat([lam_d, status.to(torch.float64), flag.to(torch.float64)])
+            item["head"] = torch.empty(head.numel(), dtype=torch.float64).pin_memory()
+            item["head"].copy_(head, non_blocking=True)
+            item["_keep"] = (lam_d, status, flag, head)
+            item["e"] = torch.cuda.Event(enable_timing=True)
+            item["e"].record()
+
+    def _backproject(self, item):
+        ctx, st = (self.ctxG, self.sG) if self.backproject_on == "gram" else (self.ctxE, self.sE)
+        with ctx.use(st):
+            st.wait_event(item["e"])
+            item["Q"] = ops.gemm_nn(item["X"], item["Zs"])
+            item["b"] = torch.cuda.Event(enable_timing=True)
+            item["b"].record()
+
+    def _finish(self, item):
+        item["b"].synchronize()
+        n, k = item["X"].shape[1], item["k"]
+        head = item["head"].numpy()
+        lam, status, zero_norm = head[:n], int(head[n]), int(head[n + 1])
+        if item["normalize"] and zero_norm:
+            raise ValueError("array must not contain infs or NaNs (zero-norm snapshot with normalize=True)")
+        s = np.sqrt(np.clip(lam, 0.0, None))
+        energy = pod._energy(s)
+        gaps = lam[:k] - lam[1:k + 1] if k < n else np.r_[lam[:k - 1] - lam[1:k], lam[k - 1]]
+        ok = (status == 0 and s[0] > 0 and s[k - 1] >= pod.TWO_PASS_RATIO * s[0]
+              and gaps.min() >= pod.RR_GAP * max(lam[0], 1e-300) and item["X"].shape[0] >= n)
+        self.last_stage_ms = dict(gram_ms=item["t0"].elapsed_time(item["g"]), eig_ms=item["g"].elapsed_time(item["e"]),
+                                  gram_to_done_ms=item["t0"].elapsed_time(item["b"]))
+        if not ok:
+            # what pod_device decides after the fact too: this spectrum needs deflated levels / a Rayleigh-Ritz step
+            self.recomputed += 1
+            return pod.pod_device(item["X"], num=item["num"], normalize=item["normalize"])
+        return dict(Q=item["Q"], s=s, energy=energy, VT=None, r=k, passes=1, colnorm=item["colnorm"])
+
+    # ---- driver -----------------------------------------------------------------------------------------------
+    def run(self, snapshot_sets, num, normalize=True, depth=2):
+        """Generator over the results (dicts as ``pod.pod_device`` returns) of ``orth(X, num=num, normalize=normalize)``
+        for every X of ``snapshot_sets`` (float64 CUDA tensors, N x n), in order.  ``depth`` sets are in flight."""
+        if not num:
+            raise ValueError("PodPipeline enqueues ahead of the spectrum: it needs `num` (pod.py:51-53)")
+        main = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(main)                       # the snapshot sets were produced on the caller's stream
+        self.sG.wait_event(ready)
+        self.sE.wait_event(ready)
+        flight = collections.deque()
+        it = iter(snapshot_sets)
+
+        def admit():
+            try:
+                X = next(it)
+            except StopIteration:
+                return None
+            if X.dim() != 2 or not X.is_cuda or X.dtype != torch.float64:
+                raise _lib.RomtimeHipError("PodPipeline takes 2-D float64 CUDA tensors")
+            item = dict(X=X, num=num, k=int(min(num, X.shape[1])), normalize=bool(normalize))
+            self._gram(item)
+            return item
+
+        nxt = admit()
+        while nxt is not None:
+            cur = nxt
+            self._eig(cur)
+            nxt = admit()                        # Gram of the next set goes onto stream G BEFORE this set's back-projection
+            self._backproject(cur)
+            flight.append(cur)
+            while len(flight) > depth or (nxt is None and flight):
+                yield self._finish(flight.popleft())
+        done = torch.cuda.Event()
+        done.record(self.sG)
+        main.wait_event(done)                    # results are safe to use on the caller's stream
+        done2 = torch.cuda.Event()
+        done2.record(self.sE)
+        main.wait_event(done2)
+
+    def map(self, snapshot_sets, num, normalize=True, depth=2):
+        return list(self.run(snapshot_sets, num, normalize=normalize, depth=depth))
