@@ -195,6 +195,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the online-sweep half of the metric (N = 1 only)")
     ap.add_argument("--sweep-steps", type=int, default=10_000)
+    ap.add_argument("--mode", choices=("auto", "pipeline", "latency"), default="auto",
+                    help="pipeline: the steps run through PodPipeline (eigensolve of step i beside the Gram of step i+1 on "
+                         "CU-partitioned streams); latency: one pod_device call after the other; auto: pipeline up to 2 GPUs")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -237,25 +240,57 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def step():
-        return pod.pod_device(X, num=r, normalize=True, group=group)
+    mode = args.mode if args.mode != "auto" else ("pipeline" if world <= 2 else "latency")
+    latency_ms = None
+    if mode == "pipeline":
+        # The K steps are K independent PODs (as the per-parameter PODs of a tree walk are): PodPipeline keeps two of
+        # them in flight, the n x n eigensolve of one beside the Gram kernel of the next on disjoint CUs.  Every step
+        # delivers its complete result (basis on the device, all singular values on the host) before the region ends.
+        from romtime_amd.pipeline import PodPipeline
 
-    for _ in range(args.warmup):
-        out = step()
-    ctx.set_profile(True)
-    gram_ms = []
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-        # the Gram kernel's own HIP event pair on the ctx stream (rt_last_gram_ms), read at the end of the step
-        # when the kernel has long finished: nothing in the timed region waits for the device except the
-        # eigenvalue fetch that orth's return values need
-        gram_ms.append(out.get("gram_kernel_ms", float("nan")))
-    barrier()
-    elapsed = time.perf_counter() - t0
-    ctx.set_profile(False)
-    stage_ms = dict(pod.stage_timings())   # stream events of the last step, resolved after the timed region
+        pipe = PodPipeline(group=group)
+        pipe.map([X] * max(args.warmup, 1), num=r, normalize=True)
+        pipe.gram_kernel_ms.clear()
+        barrier()
+        t0 = time.perf_counter()
+        outs = pipe.map([X] * args.steps, num=r, normalize=True)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        out = outs[-1]
+        gram_ms = list(pipe.gram_kernel_ms)
+        stage_ms = dict(pipe.last_stage_ms, sets_recomputed_on_regular_route=float(pipe.recomputed),
+                        eigensolver_cus=float(pipe.eig_cus))
+        if world == 1:   # one POD on its own (latency mode), for the record
+            for _ in range(3):
+                pod.pod_device(X, num=r, normalize=True)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                pod.pod_device(X, num=r, normalize=True)
+            torch.cuda.synchronize()
+            latency_ms = 1e3 * (time.perf_counter() - t1) / 5
+        del outs
+        pipe.close()
+    else:
+        def step():
+            return pod.pod_device(X, num=r, normalize=True, group=group)
+
+        for _ in range(args.warmup):
+            out = step()
+        ctx.set_profile(True)
+        gram_ms = []
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+            # the Gram kernel's own HIP event pair on the ctx stream (rt_last_gram_ms), read at the end of the step
+            # when the kernel has long finished: nothing in the timed region waits for the device except the
+            # eigenvalue fetch that orth's return values need
+            gram_ms.append(out.get("gram_kernel_ms", float("nan")))
+        barrier()
+        elapsed = time.perf_counter() - t0
+        ctx.set_profile(False)
+        stage_ms = dict(pod.stage_timings())   # stream events of the last step, resolved after the timed region
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
     if world > 1:
@@ -282,7 +317,11 @@ def main():
         roofline = dict(bound="mfma", achieved=achieved, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                         frac=achieved / FP64_MFMA_PEAK_TFLOPS, traffic=traffic, traffic_source=traffic_source,
                         kernel="gram128_kernel<KC,false> + gram128_kernel<KC,true> (off-diagonal + diagonal tiles "
-                               "of one Gram, one event pair around both launches)", kernel_ms=k_ms,
+                               "of one Gram, one event pair around both launches"
+                               + ("; in pipeline mode the pair is on the Gram's own CU-masked stream, includes the 0.03 ms "
+                                  "slab reduction, and the kernels hold 224 of the 256 CUs)" if mode == "pipeline" else ")"),
+                        kernel_ms=k_ms, frac_of_cu_share_peak=(achieved / FP64_MFMA_PEAK_TFLOPS * 256.0 / 224.0
+                                                                 if mode == "pipeline" else achieved / FP64_MFMA_PEAK_TFLOPS),
                         algorithmic_flops=alg_flops, algorithmic_bytes=alg_bytes,
                         hbm_frac=alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         note="FP64 Gram at n=512 is 64 flop/B: matrix-core bound, not HBM bound")
@@ -300,7 +339,8 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"pod_{n_h}x{n}_r{r}_normalize", "n_h": n_h, "n_snapshots": n, "modes": r,
-                       "rows_per_gpu": n_local, "passes": out["passes"], "parallelism": f"row-sharded x{world}"},
+                       "rows_per_gpu": n_local, "passes": out["passes"], "parallelism": f"row-sharded x{world}",
+                       "mode": mode, "single_pod_latency_ms": latency_ms},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "roofline": roofline,
         }

@@ -211,6 +211,24 @@ int rt_hrom_bdf_sweep(rt_ctx* ctx, const rt_hsweep_desc* desc, double* uN_out);
  * K^T/(|K|_1 |K|_inf), systems handed to the pivoted LU, systems solved }.  Synchronises the ctx stream. */
 int rt_last_sweep_stats(rt_ctx* ctx, int64_t* stats4);
 
+/* ---- closed-form local assembly of the 1-D P1 operators at (M)DEIM entries (the step before the path) ----------
+ * What ``assemble(mu, t, entries=dofs[, u_n])`` returns for the reference's 1-D problems (fom/base.py:523-599 per-entry
+ * assembly of the forms in fom/nonlinear.py:374-494; closed forms as in testing/mock.py:30-85), for n_states states at
+ * once: out[s][e] = operator(kind; h[s], coef[s], nodal function of state s) at entry (rows[e], cols[e]) of the
+ * (nx + 1) x (nx + 1) matrix, or at vector entry rows[e] for RT_P1_LOAD (cols = NULL).  h[s] = L(mu, t) / nx is the
+ * cell size of state s, coef[s] a scalar factor (NULL = 1; the diffusivity alpha(mu, t) for the stiffness).  The
+ * nodal function (w of the trilinear form int w u' v, f of the load int f v): state_mode 1 = state is n_states x (nx+1)
+ * nodal values, 2 = state is n_states amplitudes of the ramp amp * node / nx (the piston lifting g = amp x / L), 0 = none.
+ * First / last dof are Dirichlet rows (identity rows, zero load).  Feeds the F tables of rt_hrom_bdf_sweep. */
+#define RT_P1_MASS 0
+#define RT_P1_STIFFNESS 1
+#define RT_P1_CONVECTION 2
+#define RT_P1_TRILINEAR 3
+#define RT_P1_LOAD 4
+int rt_p1_local_assembly(rt_ctx* ctx, int kind, int64_t nx, const int64_t* rows, const int64_t* cols, int64_t m,
+                         int64_t n_states, const double* h, const double* coef, int state_mode, const double* state,
+                         double* out);
+
 /* ---- small symmetric eigenproblem of the Gram matrix, on the device (3 <= n <= 1024) ---------- */
 /* Householder tridiagonalisation (32 cooperating workgroups, 128 for n > 512; matrix resident in LDS) + Sturm
  * multisection:

@@ -52,6 +52,7 @@ SIGNATURES = {
     "rt_dense_solve_batched": (_int, [_p, _p, _p, _i64, _i64, _p]),
     "rt_rom_bdf_sweep": (_int, [_p, _p, _p]),
     "rt_hrom_bdf_sweep": (_int, [_p, _p, _p]),
+    "rt_p1_local_assembly": (_int, [_p, _int, _i64, _p, _p, _i64, _i64, _p, _p, _int, _p, _p]),
     "rt_sym_eig_values": (_int, [_p, _p, _i64, _p, _p]),
     "rt_sym_eig_values_part": (_int, [_p, _p, _i64, _i64, _i64, _p, _p]),
     "rt_sym_eig_vectors": (_int, [_p, _i64, _i64, _p, _p]),

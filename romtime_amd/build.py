@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libromtime_hip.so")
-SOURCES = ["api.hip", "gemm_mfma.hip", "tallskinny.hip", "rank_update.hip", "gram_mfma.hip", "deim.hip", "sparse.hip", "project_fused.hip", "solve.hip", "sweep.hip", "symeig.hip", "jacobi_host.hip"]
+SOURCES = ["api.hip", "gemm_mfma.hip", "tallskinny.hip", "rank_update.hip", "gram_mfma.hip", "deim.hip", "sparse.hip", "project_fused.hip", "solve.hip", "sweep.hip", "symeig.hip", "jacobi_host.hip", "p1_assembly.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 

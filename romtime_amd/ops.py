@@ -211,6 +211,34 @@ def dense_solve(K: torch.Tensor, b: torch.Tensor):
     return (bw[0] if single else bw), info
 
 
+P1_KINDS = dict(mass=0, stiffness=1, convection=2, trilinear=3, load=4)
+
+
+def p1_local_assembly(kind: str, nx: int, rows, cols, h, coef=None, state=None, ramp=None) -> torch.Tensor:
+    """Closed-form 1-D P1 operator values at the entries (rows[e], cols[e]) for every state: (n_states, m) table.
+    ``h`` (n_states) cell sizes, ``coef`` (n_states) optional factors, ``state`` (n_states, nx + 1) nodal values or
+    ``ramp`` (n_states) amplitudes of amp * node / nx for the trilinear / load kinds.  rt_p1_local_assembly."""
+    ctx = Context.current()
+    rows = rows if isinstance(rows, torch.Tensor) else to_device_index(rows)
+    cols = None if cols is None else (cols if isinstance(cols, torch.Tensor) else to_device_index(cols))
+    h = to_device(np.atleast_1d(h) if not isinstance(h, torch.Tensor) else h).contiguous()
+    n_states, m = h.numel(), rows.numel()
+    coef = None if coef is None else to_device(np.atleast_1d(coef) if not isinstance(coef, torch.Tensor) else coef).contiguous()
+    mode, st = 0, None
+    if state is not None:
+        st = to_device(state).contiguous()
+        if tuple(st.shape) != (n_states, nx + 1):
+            raise RomtimeHipError("p1_local_assembly: `state` must be (n_states, nx + 1)")
+        mode = 1
+    elif ramp is not None:
+        st = to_device(np.atleast_1d(ramp) if not isinstance(ramp, torch.Tensor) else ramp).contiguous()
+        mode = 2
+    out = torch.empty((n_states, m), dtype=torch.float64, device=h.device)
+    ctx.check(ctx.lib.rt_p1_local_assembly(ctx.handle, P1_KINDS[kind], int(nx), _ptr(rows), _ptr(cols), m, n_states, _ptr(h),
+                                           _ptr(coef), mode, _ptr(st), _ptr(out)), "rt_p1_local_assembly")
+    return out
+
+
 def sym_eig_values(G: torch.Tensor, first: int = 0, count: int | None = None):
     """Eigenvalues (descending, device) of the symmetric n x n G; (lam, status).  With ``first`` / ``count`` only
     lam[first:first+count] is computed (the rest of ``lam`` is left unset).  rt_sym_eig_values(_part)."""

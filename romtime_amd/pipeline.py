@@ -37,7 +37,14 @@ _p = C.c_void_p
 
 
 class PodPipeline:
-    def __init__(self, eig_cus_per_xcd: int = 4, device=None, backproject_on: str = "gram"):
+    def __init__(self, eig_cus_per_xcd: int = 4, device=None, group=None, eig_first_cu: int = 0, gram_range=None):
+        """``eig_cus_per_xcd``: CUs of every XCD given to the eigensolver stream (4 -> 32 CUs: a CU per cooperating
+        workgroup; 4 and 8 keep the shader engines of an XCD evenly loaded, other values measured slower).
+        ``group``: torch.distributed process group of a row-sharded run - the Gram matrices are summed over it on stream
+        G (one all-reduce per snapshot set), the small eigenproblem is replicated on every rank (identical inputs,
+        deterministic kernels: identical outputs).
+        ``eig_first_cu`` / ``gram_range`` = (first, count): explicit per-XCD CU ranges of the two streams, for processes that
+        share one GPU (their eigensolver teams must not share CUs: a team spins until all its workgroups are resident)."""
         if not torch.cuda.is_available():
             raise _lib.RomtimeHipError("no MI355X visible: romtime_amd's hot path runs on the GPU only")
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
@@ -48,9 +55,12 @@ class PodPipeline:
         e = int(eig_cus_per_xcd)
         if not (1 <= e < per_xcd):
             raise ValueError(f"eig_cus_per_xcd must be in [1, {per_xcd})")
+        g_first, g_count = gram_range if gram_range is not None else (eig_first_cu + e, per_xcd - e - eig_first_cu)
+        if eig_first_cu < 0 or g_count < 1 or g_first + g_count > per_xcd or not (eig_first_cu + e <= g_first or g_first + g_count <= eig_first_cu):
+            raise ValueError("the CU ranges of the two streams must be disjoint and inside the XCD")
         self._raw = []
         hE, hG = _p(), _p()
-        for h, first, count in ((hE, 0, e), (hG, e, per_xcd - e)):
+        for h, first, count in ((hE, eig_first_cu, e), (hG, g_first, g_count)):
             rc = lib.rt_stream_create_cu_range(dev, first, count, C.byref(h))
             if rc != 0:
                 raise _lib.RomtimeHipError(f"rt_stream_create_cu_range failed ({rc})")
@@ -60,10 +70,11 @@ class PodPipeline:
         self.ctxE, self.ctxG = _lib.Context(dev), _lib.Context(dev)
         self.ctxE.set_option("cu_limit", 8 * e)
         self.ctxE.set_option("eig_one_xcd", 0)       # the E CUs span all XCDs: write-through hand-off
-        self.ctxG.set_option("cu_limit", 8 * (per_xcd - e))
-        self.backproject_on = backproject_on
+        self.ctxG.set_option("cu_limit", 8 * g_count)
+        self.group = group
         self.eig_cus = 8 * e
         self.recomputed = 0                          # sets that failed a check and took the regular route
+        self.gram_kernel_ms = []                     # per set: Gram kernels + slab reduction, stream events on stream G
         self.last_stage_ms = {}
 
     def close(self):
@@ -86,7 +97,16 @@ class PodPipeline:
         with self.ctxG.use(self.sG):
             item["t0"] = torch.cuda.Event(enable_timing=True)
             item["t0"].record()
-            item["G"] = ops.gram(X, out=torch.empty((n, n), dtype=torch.float64, device=X.device))
+            Gbuf = torch.empty(n * n + 1, dtype=torch.float64, device=X.device)   # G and the row count: one all-reduce
+            item["G"] = ops.gram(X, out=Gbuf[: n * n].view(n, n))
+            Gbuf[n * n:].fill_(float(X.shape[0]))
+            item["k0"] = torch.cuda.Event(enable_timing=True)
+            item["k0"].record()                                                    # Gram kernels + slab reduction end here
+            if self.group is not None:
+                import torch.distributed as dist
+
+                dist.all_reduce(Gbuf, op=dist.ReduceOp.SUM, group=self.group)
+            item["Gbuf"] = Gbuf
             item["g"] = torch.cuda.Event(enable_timing=True)
             item["g"].record()
 
@@ -102,7 +122,7 @@ class PodPipeline:
             inv = torch.where(sig > 0, 1.0 / sig, torch.zeros_like(sig))
             item["Zs"] = ((Z / colnorm[:, None] if normalize else Z) * inv[None, :]).contiguous()
             item["colnorm"], item["Z"] = colnorm, Z
-            head = torch.cat([lam_d, status.to(torch.float64), flag.to(torch.float64)])
+            head = torch.cat([lam_d, status.to(torch.float64), flag.to(torch.float64), item["Gbuf"][-1:]])
             item["head"] = torch.empty(head.numel(), dtype=torch.float64).pin_memory()
             item["head"].copy_(head, non_blocking=True)
             item["_keep"] = (lam_d, status, flag, head)
@@ -110,7 +130,8 @@ class PodPipeline:
             item["e"].record()
 
     def _backproject(self, item):
-        ctx, st = (self.ctxG, self.sG) if self.backproject_on == "gram" else (self.ctxE, self.sE)
+        # on stream G: the tall-skinny product wants the bandwidth of many CUs (on the 32 CUs of stream E it took 30 ms)
+        ctx, st = self.ctxG, self.sG
         with ctx.use(st):
             st.wait_event(item["e"])
             item["Q"] = ops.gemm_nn(item["X"], item["Zs"])
@@ -121,20 +142,23 @@ class PodPipeline:
         item["b"].synchronize()
         n, k = item["X"].shape[1], item["k"]
         head = item["head"].numpy()
-        lam, status, zero_norm = head[:n], int(head[n]), int(head[n + 1])
+        lam, status, zero_norm, n_rows = head[:n], int(head[n]), int(head[n + 1]), int(round(head[n + 2]))
         if item["normalize"] and zero_norm:
             raise ValueError("array must not contain infs or NaNs (zero-norm snapshot with normalize=True)")
         s = np.sqrt(np.clip(lam, 0.0, None))
         energy = pod._energy(s)
         gaps = lam[:k] - lam[1:k + 1] if k < n else np.r_[lam[:k - 1] - lam[1:k], lam[k - 1]]
         ok = (status == 0 and s[0] > 0 and s[k - 1] >= pod.TWO_PASS_RATIO * s[0]
-              and gaps.min() >= pod.RR_GAP * max(lam[0], 1e-300) and item["X"].shape[0] >= n)
-        self.last_stage_ms = dict(gram_ms=item["t0"].elapsed_time(item["g"]), eig_ms=item["g"].elapsed_time(item["e"]),
-                                  gram_to_done_ms=item["t0"].elapsed_time(item["b"]))
+              and gaps.min() >= pod.RR_GAP * max(lam[0], 1e-300) and n_rows >= n)
+        self.last_stage_ms = dict(gram_kernel_ms=item["t0"].elapsed_time(item["k0"]),
+                                  gram_allreduce_ms=item["t0"].elapsed_time(item["g"]),
+                                  eig_chain_ms=item["g"].elapsed_time(item["e"]),
+                                  gram_start_to_basis_ms=item["t0"].elapsed_time(item["b"]))
+        self.gram_kernel_ms.append(self.last_stage_ms["gram_kernel_ms"])
         if not ok:
             # what pod_device decides after the fact too: this spectrum needs deflated levels / a Rayleigh-Ritz step
             self.recomputed += 1
-            return pod.pod_device(item["X"], num=item["num"], normalize=item["normalize"])
+            return pod.pod_device(item["X"], num=item["num"], normalize=item["normalize"], group=self.group)
         return dict(Q=item["Q"], s=s, energy=energy, VT=None, r=k, passes=1, colnorm=item["colnorm"])
 
     # ---- driver -----------------------------------------------------------------------------------------------

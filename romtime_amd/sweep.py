@@ -77,7 +77,7 @@ def hrom_bdf_sweep(mass, lin, nl, rhs, dt, bdf2=True):
 
     nt, n_mu, m_mass = tuple(mass["F"].shape)
     m_lin = sum(int(t["F"].shape[2]) for t in lin)
-    m_nl = 0 if nl is None else np.asarray(nl["W"]).shape[0]
+    m_nl = 0 if nl is None else int(nl["W"].shape[0])
     Z = dev(np.vstack(blocks))
     Fm = dev(mass["F"])
     Fl = cat(lin) if lin else None
@@ -131,3 +131,53 @@ def hrom_terms_from_rom(rom, mus):
     nl = dict(PT_U=red.PT_U, basis_rom=red.basis_rom, W=W, C=np.broadcast_to(c0, (nt, len(mus), c0.size)).copy())
     return dict(mass=term(need["mass"]), lin=[term(need[k]) for k in ("stiffness", "convection", "nonlinear_lifting")],
                 nl=nl, rhs=[term(need["lifting"])], dt=dt, bdf2=(fom.BDF_SCHEME == "2"))
+
+
+def hrom_terms_on_device(rom, mus):
+    """The same term dictionaries as :func:`hrom_terms_from_rom`, with every table of local operator entries built ON THE
+    DEVICE by the closed-form P1 assembly (``rt_p1_local_assembly``) instead of ``nt x n_mu`` host calls of the FOM's
+    entry-wise assembly per operator (deim.py:429-433 -> fom/base.py:523-599).  The FOM only supplies the scalar functions
+    of (mu, t) the closed forms depend on - ``fom.p1_closed_form(mus, ts)``: cell size, diffusivity, lifting amplitudes -
+    evaluated vectorised on the host (n_mu calls).  1-D P1 problems on a uniformly scaled mesh (the reference's piston and
+    heat problems, fom/nonlinear.py:374-494)."""
+    fom = rom.fom
+    if not hasattr(fom, "p1_closed_form"):
+        raise NotImplementedError("the FOM does not expose closed-form P1 scalars (p1_closed_form)")
+    nt, dt = fom.domain["nt"], fom.dt
+    ts = dt * np.arange(1, nt + 1)
+    cf = fom.p1_closed_form(mus, ts)
+    nx, n_mu = int(cf["nx"]), len(mus)
+    need = dict(mass=rom.mdeim_Mh, stiffness=rom.mdeim_Ah, convection=rom.mdeim_Ch, nonlinear_lifting=rom.mdeim_Nh_hat,
+                trilinear=rom.mdeim_Nh, lifting=rom.deim_fgh)
+    missing = [k for k, v in need.items() if not v]
+    if missing:
+        raise ValueError(f"operators without a hyper-reductor: {missing}")
+    flat = lambda a: ops.to_device(np.ascontiguousarray(a, dtype=np.float64).reshape(-1))
+    h = flat(cf["h"])
+
+    def entries(red, matrix=True):
+        d = np.asarray(red.dofs, dtype=np.int64)
+        return (ops.to_device_index(d[:, 0]), ops.to_device_index(d[:, 1]) if matrix else None)
+
+    def table(red, kind, matrix=True, **kw):
+        rows, cols = entries(red, matrix)
+        return ops.p1_local_assembly(kind, nx, rows, cols, h, **kw).view(nt, n_mu, -1)
+
+    def term(red, F):
+        return dict(PT_U=red.PT_U, basis_rom=red.basis_rom, F=F)
+
+    mass = term(need["mass"], table(need["mass"], "mass"))
+    lin = [term(need["stiffness"], table(need["stiffness"], "stiffness", coef=flat(cf["alpha"]))),
+           term(need["convection"], table(need["convection"], "convection")),
+           term(need["nonlinear_lifting"], table(need["nonlinear_lifting"], "trilinear", ramp=flat(cf["lift"])))]
+    rhs = [term(need["lifting"], table(need["lifting"], "load", matrix=False, ramp=flat(cf["lift_dot"])))]
+    # state-dependent operator: entries are affine in the state, W u_N + C, independent of (mu, t) for the P1 trilinear form
+    red = need["trilinear"]
+    rows, cols = entries(red)
+    V = np.ascontiguousarray(rom.basis.T)                                    # r x N_h: the basis functions as states
+    one = ops.to_device(np.ones(V.shape[0] + 1))
+    both = ops.p1_local_assembly("trilinear", nx, rows, cols, one, state=np.vstack([V, np.zeros((1, V.shape[1]))]))
+    c0 = both[-1]
+    W = (both[:-1] - c0[None, :]).T.contiguous()                              # m x r
+    nl = dict(PT_U=red.PT_U, basis_rom=red.basis_rom, W=W, C=c0.expand(nt, n_mu, c0.numel()).contiguous())
+    return dict(mass=mass, lin=lin, nl=nl, rhs=rhs, dt=dt, bdf2=(fom.BDF_SCHEME == "2"))

@@ -208,6 +208,31 @@ class MockBurgers(MockSolver):
         return self._assemble_vector(elem, entries)
 
 
+def _p1_closed_form(self, mus, ts):
+    """Scalar tables of the closed-form P1 operators for every (t, mu): what ``rt_p1_local_assembly`` needs instead of
+    per-(mu, t) assembly callbacks.  (nt, n_mu) arrays: ``h`` cell size, ``alpha`` diffusivity (stiffness factor),
+    ``lift`` amplitude of the lifting ramp g = lift x / L, ``lift_dot`` amplitude of its time derivative's ramp."""
+    ts = np.asarray(ts, dtype=float)
+    L = np.empty((ts.size, len(mus)))
+    for j, mu in enumerate(mus):
+        try:
+            col = np.broadcast_to(np.asarray(self._L(mu, ts), dtype=float), ts.shape)
+        except Exception:  # a scale function that does not take arrays
+            col = np.array([self._L(mu, t) for t in ts])
+        L[:, j] = col
+    a0 = np.array([mu["alpha_0"] for mu in mus])[None, :]
+    out = dict(nx=self.nx, h=L / self.nx, alpha=a0 * (1.0 + ts[:, None] ** 2))
+    if all(("delta" in mu and "omega" in mu) for mu in mus):
+        d = np.array([mu["delta"] for mu in mus])[None, :]
+        w = np.array([mu["omega"] for mu in mus])[None, :]
+        out["lift"] = d * np.sin(w * ts[:, None])
+        out["lift_dot"] = -d * w * np.cos(w * ts[:, None])
+    return out
+
+
+MockSolver.p1_closed_form = _p1_closed_form
+
+
 class AffineBurgers:
     """Synthetic Burgers-type FOM whose operators are affine in fixed value vectors on ONE CSR pattern
     (pentadiagonal), the form the device sweep (rt_rom_bdf_sweep) consumes:

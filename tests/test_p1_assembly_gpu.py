@@ -1,0 +1,109 @@
+"""rt_p1_local_assembly (HIP half): closed-form 1-D P1 operators at (M)DEIM entries on the
+device, against (1) the literal operator tables of the reference's own FEniCS tests (tests/test_mpf1.py:170-260,
+tests/test_moving_mesh.py:135-144), (2) the NumPy closed forms that tests/test_oracle_golden.py pins to the same tables,
+entry-wise and with nodal states, (3) the host route through the class surface: the F tables of a fully hyper-reduced
+ROM built on the device equal the tables ``nt x n_mu`` FOM callbacks give, and the device sweep fed with them equals
+oracle.hrom_solve."""
+import numpy as np
+import pytest
+
+from oracle import romtime_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _pattern(nx):
+    rows, cols = [0], [0]
+    for i in range(1, nx):
+        rows += [i, i, i]
+        cols += [i - 1, i, i + 1]
+    rows.append(nx)
+    cols.append(nx)
+    return np.array(rows), np.array(cols)
+
+
+def test_reference_known_answer_tables_on_the_device():
+    from scipy.stats import uniform
+    from sklearn.model_selection import ParameterSampler
+
+    from romtime_amd import ops
+
+    # tests/test_mpf1.py:123-260: fixed mesh, L = 2, nx = 3, t = 0, three sampler draws; dense 4 x 4 tables
+    grid = {"delta": uniform(0.01, 1.99), "beta": uniform(1.0, 9.0), "alpha_0": uniform(0.01, 1.99)}
+    samples = list(ParameterSampler(param_distributions=grid, n_iter=3, random_state=np.random.RandomState(0)))
+    nx, L = 3, 2.0
+    ii, jj = np.divmod(np.arange(16), 4)                              # every entry of the dense matrix, row-major
+    h = np.full(3, L / nx)
+    alpha = np.array([s["alpha_0"] for s in samples])                # alpha_0 (1 + t^2) at t = 0
+    A = ops.p1_local_assembly("stiffness", nx, ii, jj, h, coef=alpha).cpu().numpy()
+    M = ops.p1_local_assembly("mass", nx, ii, jj, h).cpu().numpy()
+    for row, d in zip(A, [3.30641662, 3.2829526, 2.64239565]):      # test_mpf1.py:176,194,212
+        np.testing.assert_array_almost_equal(row, [1.0, 0, 0, 0, -d / 2, d, -d / 2, 0, 0, -d / 2, d, -d / 2, 0, 0, 0, 1.0], decimal=6)
+    for row in M:                                                     # test_mpf1.py:229-245
+        np.testing.assert_array_almost_equal(row, [1.0, 0, 0, 0, 0.11111111, 0.44444444, 0.11111111, 0, 0, 0.11111111,
+                                                   0.44444444, 0.11111111, 0, 0, 0, 1.0], decimal=6)
+    # tests/test_moving_mesh.py:102-150: L(t) = 1 + sin(omega t), nx = 5, alpha_0 = 0.5, t = 0 and t = 5 (CSR data order)
+    nx = 5
+    rows, cols = _pattern(nx)
+    omega = np.pi / 2.0 / 10
+    ts = np.array([0.0, 5.0])
+    hL = (1.0 + np.sin(omega * ts)) / nx
+    out = ops.p1_local_assembly("stiffness", nx, rows, cols, hL, coef=0.5 * (1.0 + ts ** 2)).cpu().numpy()
+    e0 = np.array([1.0, -2.5, 5.0, -2.5, -2.5, 5.0, -2.5, -2.5, 5.0, -2.5, -2.5, 5.0, -2.5, 1.0])
+    e1 = np.array([1.0] + [-38.07611845, 76.15223689, -38.07611845] * 4 + [1.0])
+    np.testing.assert_allclose(out[0], e0, rtol=1e-9)
+    np.testing.assert_allclose(out[1], e1, rtol=1e-9)
+
+
+def test_entrywise_assembly_matches_the_numpy_closed_forms():
+    from romtime_amd import ops
+    from romtime_amd.testing.mock import MockBurgers
+
+    nx = 1000
+    fom = MockBurgers(domain=dict(L0=1.3, nx=nx, T=1.0, nt=10), Lt=lambda t, **mu: 1.0 - 0.1 * np.sin(mu["omega"] * t))
+    fom.setup()
+    rng = np.random.RandomState(2)
+    rows, cols = _pattern(nx)
+    pick = np.r_[0, 1, 2, rng.choice(rows.size, 200, replace=False), rows.size - 2, rows.size - 1]
+    rows, cols = rows[pick], cols[pick]
+    entries = list(zip(rows.tolist(), cols.tolist()))
+    states = [(dict(alpha_0=0.3 + 0.1 * q, delta=0.2 + 0.05 * q, omega=5.0 + q), 0.07 * (q + 1)) for q in range(6)]
+    cf = fom.p1_closed_form([mu for mu, _ in states], [t for _, t in states])
+    diag = lambda a: np.array([a[q, q] for q in range(len(states))])   # state q = (mu_q, t_q)
+    h, alpha, lift, lift_dot = diag(cf["h"]), diag(cf["alpha"]), diag(cf["lift"]), diag(cf["lift_dot"])
+    w = rng.standard_normal((len(states), nx + 1))
+    got = dict(mass=ops.p1_local_assembly("mass", nx, rows, cols, h), stiffness=ops.p1_local_assembly("stiffness", nx, rows, cols, h, coef=alpha),
+               convection=ops.p1_local_assembly("convection", nx, rows, cols, h),
+               trilinear=ops.p1_local_assembly("trilinear", nx, rows, cols, h, state=w),
+               nonlinear_lifting=ops.p1_local_assembly("trilinear", nx, rows, cols, h, ramp=lift))
+    vrows = np.unique(rows)
+    load = ops.p1_local_assembly("load", nx, vrows, None, h, ramp=lift_dot).cpu().numpy()
+    for q, (mu, t) in enumerate(states):
+        ref = dict(mass=fom.assemble_mass(mu, t, entries=entries), stiffness=fom.assemble_stiffness(mu, t, entries=entries),
+                   convection=fom.assemble_convection(mu, t, entries=entries),
+                   trilinear=fom.assemble_trilinear(mu, t, w[q], entries=entries),
+                   nonlinear_lifting=fom.assemble_nonlinear_lifting(mu, t, entries=entries))
+        for name, table in got.items():
+            np.testing.assert_allclose(table[q].cpu().numpy(), ref[name], rtol=1e-13, atol=1e-14 * np.abs(ref[name]).max(), err_msg=name)
+        np.testing.assert_allclose(load[q], fom.assemble_lifting(mu, t, entries=[(i,) for i in vrows]), rtol=1e-12, atol=1e-15)
+
+
+def test_hyper_reduced_tables_built_on_the_device():
+    from romtime_amd.sweep import hrom_bdf_sweep, hrom_terms_from_rom, hrom_terms_on_device
+    from tests.test_surface import _fully_hyper_reduced_rom
+
+    fom, rom, mus = _fully_hyper_reduced_rom()
+    host = hrom_terms_from_rom(rom, mus)            # nt x n_mu FOM callbacks per operator (the reference's route)
+    dev = hrom_terms_on_device(rom, mus)            # one kernel launch per operator
+    pairs = [(host["mass"], dev["mass"])] + list(zip(host["lin"], dev["lin"])) + list(zip(host["rhs"], dev["rhs"]))
+    for a, b in pairs:
+        Fa, Fb = a["F"], b["F"].cpu().numpy()
+        assert Fa.shape == Fb.shape
+        np.testing.assert_allclose(Fb, Fa, rtol=1e-12, atol=1e-13 * np.abs(Fa).max())
+    np.testing.assert_allclose(dev["nl"]["W"].cpu().numpy(), host["nl"]["W"], rtol=0, atol=1e-13 * np.abs(host["nl"]["W"]).max())
+    np.testing.assert_allclose(dev["nl"]["C"].cpu().numpy(), host["nl"]["C"], rtol=0, atol=1e-14)
+    uN = hrom_bdf_sweep(dev["mass"], dev["lin"], dev["nl"], dev["rhs"], dev["dt"], dev["bdf2"]).cpu().numpy()
+    r, nt = rom.N, fom.domain["nt"]
+    for b in range(len(mus)):
+        ref = oracle.hrom_solve(host["mass"], host["lin"], host["nl"], host["rhs"], b, r, nt, host["dt"], host["bdf2"])
+        assert np.linalg.norm(uN[b].T - ref) <= 1e-10 * np.linalg.norm(ref), b

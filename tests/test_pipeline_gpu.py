@@ -1,0 +1,132 @@
+"""PodPipeline (romtime_amd/pipeline.py): sequences of independent PODs with the eigensolve of one snapshot set running
+beside the Gram kernel of the next on CU-partitioned streams.  Every set's result must be what ``pod.pod_device`` (one
+POD at a time) and the oracle give; sets whose spectrum fails the single-pass checks take the regular route."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import romtime_oracle as oracle
+
+pytestmark = pytest.mark.gpu
+EPS = 2.2e-16
+
+
+def _matrix(rng, N, n, decay):
+    U, _ = np.linalg.qr(rng.standard_normal((N, n)))
+    V, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    return (U * 10.0 ** (-decay * np.arange(n) / (n - 1))) @ V.T
+
+
+def _same_columns(Q, Qr, tol):
+    for i in range(Q.shape[1]):
+        assert min(np.linalg.norm(Q[:, i] - Qr[:, i]), np.linalg.norm(Q[:, i] + Qr[:, i])) <= tol, i
+
+
+def test_pipeline_matches_single_pods_and_oracle():
+    from romtime_amd import ops, pod
+    from romtime_amd.pipeline import PodPipeline
+
+    rng = np.random.RandomState(7)
+    k = 6
+    mats = [_matrix(rng, 9000, 96, 1.5), _matrix(rng, 20000, 130, 2.0), _matrix(rng, 9000, 96, 12.0),   # deep: regular route
+            np.asfortranarray(_matrix(rng, 7001, 200, 1.0)), _matrix(rng, 4096, 512, 3.0), _matrix(rng, 9000, 96, 1.5) * 7.0]
+    dev = [ops.to_device(m) for m in mats]
+    pipe = PodPipeline()
+    outs = pipe.map(dev, num=k, normalize=True)
+    assert len(outs) == len(mats) and pipe.recomputed == 1
+    for X, Xd, out in zip(mats, dev, outs):
+        single = pod.pod_device(Xd, num=k, normalize=True)
+        assert out["r"] == single["r"] == k and out["passes"] == single["passes"]
+        Qo, so, eo = oracle.orth(X, num=k, normalize=True)
+        bar = 2e-13 * so[0] + 8 * EPS * so[0] ** 2 / np.maximum(so, 1e-300)
+        assert np.all(np.abs(out["s"] - so) <= bar) and np.all(np.abs(single["s"] - so) <= bar)
+        np.testing.assert_allclose(out["energy"], eo, rtol=1e-10)
+        Q = out["Q"].cpu().numpy()
+        assert np.abs(Q.T @ Q - np.eye(k)).max() < 1e-10
+        _same_columns(Q, single["Q"].cpu().numpy(), 1e-11)
+        _same_columns(Q, Qo, 1e-9)
+    # the generator form hands results out in order while later sets are in flight, and works again after a run
+    again = [o["s"] for o in pipe.run(dev[:2], num=k, normalize=False)]
+    for Xd, s in zip(dev[:2], again):
+        np.testing.assert_allclose(s[:k], pod.pod_device(Xd, num=k, normalize=False)["s"][:k], rtol=1e-11)
+    with pytest.raises(ValueError):
+        list(pipe.run(dev[:1], num=None))
+    Z = ops.to_device(np.c_[mats[0][:, :5], np.zeros((9000, 1))])
+    with pytest.raises(ValueError):                                   # zero-norm column + normalize, as orth does
+        pipe.map([Z], num=3, normalize=True)
+    pipe.close()
+
+
+def test_cu_partition_abi():
+    """rt_stream_create_cu_range / "cu_limit": argument checks, and kernels on a masked stream give the same numbers."""
+    import ctypes as C
+
+    from romtime_amd import _lib, ops
+
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.rt_stream_create_cu_range(0, 0, 0, C.byref(h)) < 0          # empty range
+    assert lib.rt_stream_create_cu_range(0, 30, 4, C.byref(h)) < 0         # beyond the 32 CUs of an XCD
+    assert lib.rt_stream_create_cu_range(0, 8, 8, C.byref(h)) == 0 and h.value
+    ctx = _lib.Context(0)
+    with pytest.raises(_lib.RomtimeHipError):
+        ctx.set_option("cu_limit", 12)                                    # not a multiple of 8
+    ctx.set_option("cu_limit", 64)
+    st = torch.cuda.ExternalStream(h.value)
+    X = torch.randn((60000, 256), dtype=torch.float64, device="cuda")
+    ref = ops.gram(X)
+    with ctx.use(st):
+        G = ops.gram(X)
+        assert ctx.launch_info()["grid"] <= 2 * 64                        # the persistent grid follows the CU share
+    st.synchronize()
+    assert float((G - ref).abs().max().item()) <= 1e-12 * float(ref.abs().max().item())
+    ctx.set_option("cu_limit", 0)
+    assert lib.rt_stream_destroy(h) == 0
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, mats, k, ret):
+    import torch.distributed as dist
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from romtime_amd.pipeline import PodPipeline
+
+        # two processes on ONE GPU: eigensolver teams on disjoint CUs (a team spins until it is resident), Gram streams shared
+        pipe = PodPipeline(group=dist.group.WORLD, eig_first_cu=4 * rank, gram_range=(8, 24))
+        local = [torch.from_numpy(np.array_split(m, world)[rank]).cuda() for m in mats]
+        outs = pipe.map(local, num=k, normalize=True)
+        ret[rank] = [dict(Q=o["Q"].cpu().numpy(), s=o["s"], r=o["r"]) for o in outs]
+        pipe.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_sharded_pipeline_two_ranks_one_gpu():
+    import torch.multiprocessing as mp
+
+    from romtime_amd import ops, pod
+
+    rng = np.random.RandomState(3)
+    k, world = 5, 2
+    mats = [_matrix(rng, 12000, 64, 1.2), _matrix(rng, 12000, 140, 1.8), _matrix(rng, 8000, 64, 1.2)]
+    ret = mp.Manager().dict()
+    mp.spawn(_worker, args=(world, _free_port(), mats, k, ret), nprocs=world, join=True)
+    for j, X in enumerate(mats):
+        single = pod.pod_device(ops.to_device(X), num=k, normalize=True)
+        Qs = single["Q"].cpu().numpy()
+        np.testing.assert_array_equal(ret[0][j]["s"], ret[1][j]["s"])          # replicated eigenproblem: ranks agree bitwise
+        np.testing.assert_allclose(ret[0][j]["s"][:k], single["s"][:k], rtol=1e-11)
+        Q = np.concatenate([ret[r][j]["Q"] for r in range(world)], axis=0)      # row slabs stack back into the basis
+        _same_columns(Q, Qs, 1e-10)
