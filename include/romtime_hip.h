@@ -93,6 +93,20 @@ int rt_gram(rt_ctx* ctx, const double* X, int64_t n_rows, int64_t n_cols, int64_
  * is set to RT_WARN_ZERO_NORM. */
 int rt_gram_scale(rt_ctx* ctx, double* G, int64_t n, double* colnorm, int normalize, int* status_flag);
 
+/* The whole of `orth` (pod.py:7-62) in one call, for hosts that bind this library without the Python layer: column
+ * norms (normalize != 0), Gram matrix, all singular values, energy curve, truncation with the reference's precedence
+ * (tol != 0: energy < tol, strict; else num != 0: first num; else sigma > 1e-7), basis.  X: n_rows x n_cols DEVICE matrix
+ * (ld, layout), n_cols <= 1024.  Q: DEVICE buffer n_rows x q_cols row-major; on return its first *r_out columns are the
+ * basis (the others are zero or unspecified); if the rule keeps more than q_cols modes the call returns RT_ERR_ARG with
+ * *r_out = the number needed.  s_host / energy_host: HOST arrays of min(n_rows, n_cols) entries - ALL singular values and
+ * the whole energy curve, as the reference returns them.  *levels_out (may be NULL): Gram passes taken (1 = single pass;
+ * more = deflated levels for spectra deeper than 1e-2).  Returns RT_WARN_ZERO_NORM (and no basis) where
+ * the reference raises on a zero-norm snapshot with normalize.  Synchronises the ctx stream (the truncation rule needs
+ * the spectrum on the host).  Single device: a row-sharded host sums the Gram matrices itself and uses the pieces below. */
+int rt_pod_orth(rt_ctx* ctx, const double* X, int64_t n_rows, int64_t n_cols, int64_t ld, int layout, int64_t num,
+                double tol, int normalize, double* Q, int64_t q_cols, int64_t* r_out, double* s_host,
+                double* energy_host, int* levels_out);
+
 /* C (m x n, row-major, ldc) = A^T B with A: N x m, B: N x n (each with ld + layout).
  * np.matmul(V.T, AhV) (utils.py:112), np.matmul(V.T, Vfh) (deim.py:509), V.T.dot(f)
  * (rom.py:133,156).  A == B with m == n computes only the upper triangle and mirrors it. */

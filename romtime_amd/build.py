@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libromtime_hip.so")
-SOURCES = ["api.hip", "gemm_mfma.hip", "tallskinny.hip", "rank_update.hip", "gram_mfma.hip", "deim.hip", "sparse.hip", "project_fused.hip", "solve.hip", "sweep.hip", "symeig.hip", "jacobi_host.hip", "p1_assembly.hip"]
+SOURCES = ["api.hip", "gemm_mfma.hip", "tallskinny.hip", "rank_update.hip", "gram_mfma.hip", "deim.hip", "sparse.hip", "project_fused.hip", "solve.hip", "sweep.hip", "symeig.hip", "host_dense.cpp", "p1_assembly.hip", "pod_orth.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 
 
@@ -35,11 +35,11 @@ def _stale(target, deps):
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_panel.h"), os.path.join(CSRC, "wave_ops.h"), os.path.join(HERE, "..", "include", "romtime_hip.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "gemm_panel.h"), os.path.join(CSRC, "wave_ops.h"), os.path.join(CSRC, "host_dense.h"), os.path.join(HERE, "..", "include", "romtime_hip.h")]
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(LIBDIR, src.replace(".hip", ".o"))
+        o = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
         objs.append(o)
         if force or _stale(o, [s] + headers):
             jobs.append([hipcc, *FLAGS, "-c", s, "-o", o])

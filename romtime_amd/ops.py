@@ -73,6 +73,27 @@ def gram_scale(G: torch.Tensor, normalize: bool):
     return colnorm, flag
 
 
+def pod_orth(X: torch.Tensor, num=None, tol=None, normalize=True, q_cols=None):
+    """The composite C entry point rt_pod_orth (the whole of pod.py:7-62 in one call): returns
+    ``(Q[:, :r] device, s host, energy host, levels)``.  The Python drop-in ``orth`` uses ``pod.pod_device`` instead (it
+    overlaps the eigenvalue fetch with the back-projection and handles process groups); this wrapper exists for parity
+    tests of what a non-Python host gets."""
+    ctx = Context.current()
+    X, ld, lay = _layout(X)
+    N, n = X.shape
+    cap = int(q_cols) if q_cols is not None else (int(min(num, n)) if (num and not tol) else min(N, n))
+    Q = torch.empty((N, max(cap, 1)), dtype=torch.float64, device=X.device)
+    length = min(N, n)
+    s, energy = np.empty(length), np.empty(length)
+    r, levels = C.c_int64(0), C.c_int(0)
+    rc = ctx.lib.rt_pod_orth(ctx.handle, _ptr(X), N, n, ld, lay, int(num or 0), float(tol or 0.0), int(bool(normalize)),
+                             _ptr(Q), cap, C.byref(r), s.ctypes.data, energy.ctypes.data, C.byref(levels))
+    if rc == _lib.WARN_ZERO_NORM:
+        raise ValueError("array must not contain infs or NaNs (zero-norm snapshot with normalize=True)")
+    ctx.check(rc, "rt_pod_orth")
+    return Q[:, : r.value], s, energy, levels.value
+
+
 def gemm_tn(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     """C = A^T B with the contraction over the rows (DoFs). rt_gemm_tn."""
     ctx = Context.current()

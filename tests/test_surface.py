@@ -539,3 +539,62 @@ def test_orth_odd_shapes_hostlogic(cpu_ops):
 @pytest.mark.gpu
 def test_orth_odd_shapes_hip():
     check_orth_odd_shapes()
+
+
+@pytest.mark.gpu
+def test_rt_pod_orth_composite_abi(golden_orth):
+    """The C entry point rt_pod_orth (the whole of orth for hosts without the Python layer) on the 48 reference-generated
+    cases - the bars of check_orth_golden - plus deep spectra (deflated levels inside the call), clustered eigenvalues
+    (Rayleigh-Ritz on the host's k x k problem), n < 3 (host Jacobi), more snapshots than DoFs, a too-small Q, zero norms."""
+    import torch
+
+    from romtime_amd import ops
+    from romtime_amd._lib import RomtimeHipError
+
+    g = golden_orth
+    for key in g["cases"]:
+        mname, bname, nname = str(key).split("__")
+        kw = _branch_kwargs(bname)
+        X = g[f"X__{mname}"]
+        Qd, s, energy, levels = ops.pod_orth(ops.to_device(X), normalize=(nname == "norm"), **kw)
+        Q = Qd.cpu().numpy()
+        gQ, gs, ge = g[f"Q__{key}"], g[f"s__{key}"], g[f"energy__{key}"]
+        knife_edge = "tol" in kw and np.abs(ge - kw["tol"]).min() < 1e-12
+        if knife_edge:
+            assert abs(Q.shape[1] - gQ.shape[1]) <= 1
+            keep = min(Q.shape[1], gQ.shape[1])
+            Q, gQ = Q[:, :keep], gQ[:, :keep]
+        assert Q.shape == gQ.shape and s.shape == gs.shape, key
+        assert np.all(np.abs(s - gs) <= 2e-13 * gs[0] + 8 * EPS * gs[0] ** 2 / np.maximum(gs, 1e-300)), key
+        assert_allclose(energy, ge, rtol=1e-10, atol=0, err_msg=str(key))
+        for i in range(Q.shape[1]):
+            err = min(np.linalg.norm(Q[:, i] - gQ[:, i]), np.linalg.norm(Q[:, i] + gQ[:, i]))
+            assert err <= pod_column_tolerance(gs, i), (key, i, err, levels)
+    rng = np.random.RandomState(5)
+    # a 4-fold cluster of leading singular values: individual vectors are arbitrary, the span is not
+    U, _ = np.linalg.qr(rng.standard_normal((3000, 20)))
+    V, _ = np.linalg.qr(rng.standard_normal((20, 20)))
+    X = (U * np.r_[np.full(4, 3.0), 10.0 ** (-0.2 * np.arange(16))]) @ V.T
+    Qd, s, e, _ = ops.pod_orth(ops.to_device(X), num=4, normalize=False)
+    Qo, so, _ = oracle.orth(X, num=4, normalize=False)
+    Q = Qd.cpu().numpy()
+    assert np.linalg.norm(Q @ (Q.T @ Qo) - Qo, 2) < 1e-10 and np.abs(Q.T @ Q - np.eye(4)).max() < 1e-12
+    for N, n, kw in [(5, 2, {}), (50, 1, {}), (40, 60, dict(num=60)), (12, 30, {}), (9000, 130, dict(num=12, normalize=False))]:
+        X = rng.standard_normal((N, n)) * 10.0 ** (-0.3 * np.arange(n))
+        for arr in (np.ascontiguousarray(X), np.asfortranarray(X)):
+            Qd, s, e, _ = ops.pod_orth(ops.to_device(arr), **kw)
+            Qr, sr, er = oracle.orth(X.copy(), **kw)
+            assert Qd.shape == Qr.shape and s.shape == sr.shape, (N, n)
+            assert np.all(np.abs(s - sr) <= 2e-13 * sr[0] + 8 * EPS * sr[0] ** 2 / np.maximum(sr, 1e-300))
+            Q = Qd.cpu().numpy()
+            if Q.shape[1]:
+                assert np.linalg.norm(Q @ (Q.T @ Qr) - Qr, 2) < 1e-9
+    with pytest.raises(RomtimeHipError):                       # the rule keeps 6 modes, Q holds 2: RT_ERR_ARG
+        ops.pod_orth(ops.to_device(rng.standard_normal((200, 6))), q_cols=2)
+    Z = rng.standard_normal((50, 6))
+    Z[:, 2] = 0.0
+    with pytest.raises(ValueError):
+        ops.pod_orth(ops.to_device(Z), normalize=True)
+    Xd = torch.from_numpy(rng.standard_normal((500, 8))).cuda()
+    Qd, s, e, levels = ops.pod_orth(Xd, num=3)
+    assert Qd.is_cuda and Qd.shape == (500, 3) and levels == 1
