@@ -31,7 +31,7 @@ def test_pipeline_matches_single_pods_and_oracle():
 
     rng = np.random.RandomState(7)
     k = 6
-    mats = [_matrix(rng, 9000, 96, 1.5), _matrix(rng, 20000, 130, 2.0), _matrix(rng, 9000, 96, 12.0),   # deep: regular route
+    mats = [_matrix(rng, 9000, 96, 1.5), _matrix(rng, 20000, 130, 2.0), _matrix(rng, 9000, 96, 60.0),   # deep: regular route
             np.asfortranarray(_matrix(rng, 7001, 200, 1.0)), _matrix(rng, 4096, 512, 3.0), _matrix(rng, 9000, 96, 1.5) * 7.0]
     dev = [ops.to_device(m) for m in mats]
     pipe = PodPipeline()
