@@ -36,6 +36,20 @@ from . import _lib, ops, pod
 _p = C.c_void_p
 
 
+_STREAMS: dict = {}
+
+
+def _masked_stream(lib, dev, first, count):
+    key = (dev, first, count)
+    if key not in _STREAMS:
+        h = _p()
+        rc = lib.rt_stream_create_cu_range(dev, first, count, C.byref(h))
+        if rc != 0:
+            raise _lib.RomtimeHipError(f"rt_stream_create_cu_range({first}, {count}) failed ({rc})")
+        _STREAMS[key] = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", dev))
+    return _STREAMS[key]
+
+
 class PodPipeline:
     def __init__(self, eig_cus_per_xcd: int = 4, device=None, group=None, eig_first_cu: int = 0, gram_range=None):
         """``eig_cus_per_xcd``: CUs of every XCD given to the eigensolver stream (4 -> 32 CUs: a CU per cooperating
@@ -58,15 +72,11 @@ class PodPipeline:
         g_first, g_count = gram_range if gram_range is not None else (eig_first_cu + e, per_xcd - e - eig_first_cu)
         if eig_first_cu < 0 or g_count < 1 or g_first + g_count > per_xcd or not (eig_first_cu + e <= g_first or g_first + g_count <= eig_first_cu):
             raise ValueError("the CU ranges of the two streams must be disjoint and inside the XCD")
-        self._raw = []
-        hE, hG = _p(), _p()
-        for h, first, count in ((hE, eig_first_cu, e), (hG, g_first, g_count)):
-            rc = lib.rt_stream_create_cu_range(dev, first, count, C.byref(h))
-            if rc != 0:
-                raise _lib.RomtimeHipError(f"rt_stream_create_cu_range failed ({rc})")
-            self._raw.append(h)
-        self.sE = torch.cuda.ExternalStream(hE.value, device=self.device)
-        self.sG = torch.cuda.ExternalStream(hG.value, device=self.device)
+        # The masked streams live as long as the process: torch's caching allocator remembers the stream every block
+        # was allocated on, so a stream must outlive all tensors produced under it (destroying one made the allocator's
+        # teardown abort).  They are cached per (device, CU range) and shared by all pipelines.
+        self.sE = _masked_stream(lib, dev, eig_first_cu, e)
+        self.sG = _masked_stream(lib, dev, g_first, g_count)
         self.ctxE, self.ctxG = _lib.Context(dev), _lib.Context(dev)
         self.ctxE.set_option("cu_limit", 8 * e)
         self.ctxE.set_option("eig_one_xcd", 0)       # the E CUs span all XCDs: write-through hand-off
@@ -78,17 +88,8 @@ class PodPipeline:
         self.last_stage_ms = {}
 
     def close(self):
+        """Wait for everything in flight (the streams themselves are process-wide, see __init__)."""
         torch.cuda.synchronize(self.device)
-        for h in self._raw:
-            self.lib.rt_stream_destroy(h)
-        self._raw = []
-
-    def __del__(self):
-        try:
-            if self._raw:
-                self.close()
-        except Exception:
-            pass
 
     # ---- stages ----------------------------------------------------------------------------------------------
     def _gram(self, item):
