@@ -195,6 +195,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the online-sweep half of the metric (N = 1 only)")
     ap.add_argument("--sweep-steps", type=int, default=10_000)
+    ap.add_argument("--no-latency", action="store_true",
+                    help="pipeline mode: skip the 8 single-POD (latency mode) runs after the timed region - used under "
+                         "rocprofv3 so that the kernel statistics are those of the timed region's kernels only")
     ap.add_argument("--mode", choices=("auto", "pipeline", "latency"), default="auto",
                     help="pipeline: the steps run through PodPipeline (eigensolve of step i beside the Gram of step i+1 on "
                          "CU-partitioned streams); latency: one pod_device call after the other; auto: pipeline up to 2 GPUs")
@@ -256,11 +259,11 @@ def main():
         outs = pipe.map([X] * args.steps, num=r, normalize=True)
         barrier()
         elapsed = time.perf_counter() - t0
-        out = outs[-1]
+        out = dict(passes=outs[-1]["passes"])
         gram_ms = list(pipe.gram_kernel_ms)
         stage_ms = dict(pipe.last_stage_ms, sets_recomputed_on_regular_route=float(pipe.recomputed),
                         eigensolver_cus=float(pipe.eig_cus))
-        if world == 1:   # one POD on its own (latency mode), for the record
+        if world == 1 and not args.no_latency:   # one POD on its own (latency mode), for the record
             for _ in range(3):
                 pod.pod_device(X, num=r, normalize=True)
             torch.cuda.synchronize()
@@ -271,6 +274,10 @@ def main():
             latency_ms = 1e3 * (time.perf_counter() - t1) / 5
         del outs
         pipe.close()
+        del pipe
+        from romtime_amd import pipeline as _pipeline
+
+        _pipeline.shutdown()   # every tensor the pipeline produced is gone: the CU-masked streams can go too
     else:
         def step():
             return pod.pod_device(X, num=r, normalize=True, group=group)

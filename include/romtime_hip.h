@@ -107,6 +107,12 @@ int rt_pod_orth(rt_ctx* ctx, const double* X, int64_t n_rows, int64_t n_cols, in
                 double tol, int normalize, double* Q, int64_t q_cols, int64_t* r_out, double* s_host,
                 double* energy_host, int* levels_out);
 
+/* Zs (n x k row-major) = D^-1 W S^-1: W = Z (n x k eigenvectors of the Gram matrix, rt_sym_eig_vectors), D = diag(colnorm)
+ * (NULL: identity, normalize == False), S_j = sqrt(lam_j) (device eigenvalues; S^-1 = 0 where lam_j <= 0).  The matrix the
+ * back-projection Q = X Zs multiplies (pod.py:33,38 combined); one launch, no host data. */
+int rt_pod_backproject_weights(rt_ctx* ctx, const double* Z, int64_t n, int64_t k, const double* colnorm, const double* lam,
+                               double* Zs);
+
 /* C (m x n, row-major, ldc) = A^T B with A: N x m, B: N x n (each with ld + layout).
  * np.matmul(V.T, AhV) (utils.py:112), np.matmul(V.T, Vfh) (deim.py:509), V.T.dot(f)
  * (rom.py:133,156).  A == B with m == n computes only the upper triangle and mirrors it. */

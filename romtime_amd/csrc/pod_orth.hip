@@ -35,6 +35,20 @@ __global__ void scale_rows_cols_kernel(const double* __restrict__ Z, int n, int 
   out[idx] = v;
 }
 
+// Zs[i][j] = Z[i][j] / colnorm[i] / sqrt(lam[j])  (0 where lam[j] <= 0): the n x k matrix D^-1 W S^-1 of the back-projection,
+// straight from the device eigenvalues - nothing of it needs the host
+__global__ void backproject_weights_kernel(const double* __restrict__ Z, int n, int k, const double* __restrict__ colnorm,
+                                           const double* __restrict__ lam, double* __restrict__ out) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)n * k) return;
+  const int i = (int)(idx / k), j = (int)(idx % k);
+  const double l = lam[j];
+  const double inv = l > 0.0 ? 1.0 / sqrt(l) : 0.0;
+  double v = Z[idx];
+  if (colnorm) v /= colnorm[i];
+  out[idx] = v * inv;
+}
+
 // dst (N x n row-major) = src (N x n, strides ks / ms) * diag(1 / colnorm)   (colnorm null: plain copy)
 __global__ void copy_scaled_kernel(const double* __restrict__ src, long rs, long cs, long N, int n,
                                    const double* __restrict__ colnorm, double* __restrict__ dst) {
@@ -54,6 +68,16 @@ struct Eig {                  // eigen-decomposition of one level's Gram matrix
 };
 
 }  // namespace
+
+extern "C" int rt_pod_backproject_weights(rt_ctx* ctx, const double* Z, int64_t n, int64_t k, const double* colnorm,
+                                          const double* lam, double* Zs) {
+  if (!ctx) return RT_ERR_ARG;
+  RT_ARG_CHECK(ctx, Z && lam && Zs && n >= 1 && k >= 1 && k <= n && n * k < (1LL << 31));
+  hipLaunchKernelGGL(backproject_weights_kernel, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, ctx->stream, Z, (int)n,
+                     (int)k, colnorm, lam, Zs);
+  RT_HIP_CHECK(ctx, hipGetLastError());
+  return RT_OK;
+}
 
 extern "C" int rt_pod_orth(rt_ctx* ctx, const double* X, int64_t n_rows, int64_t n_cols, int64_t ld, int layout, int64_t num,
                            double tol, int normalize, double* Q, int64_t q_cols, int64_t* r_out, double* s_host,

@@ -94,6 +94,17 @@ def pod_orth(X: torch.Tensor, num=None, tol=None, normalize=True, q_cols=None):
     return Q[:, : r.value], s, energy, levels.value
 
 
+def backproject_weights(Z: torch.Tensor, lam: torch.Tensor, colnorm: torch.Tensor = None) -> torch.Tensor:
+    """D^-1 Z S^-1 (n x k) from the device eigenvalues ``lam`` (first k used).  rt_pod_backproject_weights."""
+    ctx = Context.current()
+    Z = Z.contiguous()
+    n, k = Z.shape
+    out = torch.empty_like(Z)
+    ctx.check(ctx.lib.rt_pod_backproject_weights(ctx.handle, _ptr(Z), n, k, _ptr(colnorm), _ptr(lam), _ptr(out)),
+              "rt_pod_backproject_weights")
+    return out
+
+
 def gemm_tn(A: torch.Tensor, B: torch.Tensor) -> torch.Tensor:
     """C = A^T B with the contraction over the rows (DoFs). rt_gemm_tn."""
     ctx = Context.current()

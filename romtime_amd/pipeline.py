@@ -39,6 +39,25 @@ _p = C.c_void_p
 _STREAMS: dict = {}
 
 
+def shutdown():
+    """Destroy the process-wide masked streams.  Call it when every tensor produced by a pipeline has been released
+    (it synchronises, collects garbage and empties torch's cache first); registered with ``atexit`` as well, because a
+    process that ends with CU-masked queues alive was seen to crash in the profiler's finaliser (rocprofv3)."""
+    import gc
+
+    if not _STREAMS:
+        return
+    try:
+        torch.cuda.synchronize()
+        gc.collect()
+        torch.cuda.empty_cache()
+        lib = _lib.load()
+        for st in list(_STREAMS.values()):
+            lib.rt_stream_destroy(_p(st.cuda_stream))
+    finally:
+        _STREAMS.clear()
+
+
 def _masked_stream(lib, dev, first, count):
     key = (dev, first, count)
     if key not in _STREAMS:
@@ -48,6 +67,11 @@ def _masked_stream(lib, dev, first, count):
             raise _lib.RomtimeHipError(f"rt_stream_create_cu_range({first}, {count}) failed ({rc})")
         _STREAMS[key] = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", dev))
     return _STREAMS[key]
+
+
+import atexit  # noqa: E402
+
+atexit.register(shutdown)
 
 
 class PodPipeline:
@@ -119,9 +143,7 @@ class PodPipeline:
             colnorm, flag = ops.gram_scale(G, normalize)
             lam_d, status = ops.sym_eig_values(G)
             Z = ops.sym_eig_vectors(lam_d, k)
-            sig = lam_d[:k].clamp_min(0.0).sqrt()
-            inv = torch.where(sig > 0, 1.0 / sig, torch.zeros_like(sig))
-            item["Zs"] = ((Z / colnorm[:, None] if normalize else Z) * inv[None, :]).contiguous()
+            item["Zs"] = ops.backproject_weights(Z, lam_d, colnorm if normalize else None)
             item["colnorm"], item["Z"] = colnorm, Z
             head = torch.cat([lam_d, status.to(torch.float64), flag.to(torch.float64), item["Gbuf"][-1:]])
             item["head"] = torch.empty(head.numel(), dtype=torch.float64).pin_memory()

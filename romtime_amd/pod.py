@@ -350,10 +350,8 @@ def pod_device(X: torch.Tensor, num=None, tol=None, normalize=True, passes=None,
         if not e.on_device or k_ahead < 1:
             return
         Z = e.raw_vectors(k_ahead)
-        sig = e.lam_d[:k_ahead].clamp_min(0.0).sqrt()
-        inv = torch.where(sig > 0, 1.0 / sig, torch.zeros_like(sig))
-        Zs = (Z / colnorm[:, None] if normalize else Z) * inv[None, :]
-        ahead_out["Q"] = ops.gemm_nn(X, Zs.contiguous())
+        Zs = ops.backproject_weights(Z, e.lam_d, colnorm if normalize else None)   # D^-1 W S^-1 in one launch
+        ahead_out["Q"] = ops.gemm_nn(X, Zs)
 
     eig = _SmallEig(G, extra=(flag, Gbuf[n * n:]), group=group, ahead=ahead if k_ahead else None)
     if prof and not k_ahead:

@@ -98,9 +98,16 @@ def dense_solve(K, b):
     return torch.from_numpy(x), torch.zeros(Kn.shape[0], dtype=torch.int32)
 
 
+def backproject_weights(Z, lam, colnorm=None):
+    k = Z.shape[1]
+    sig = lam[:k].clamp_min(0.0).sqrt()
+    inv = torch.where(sig > 0, 1.0 / sig, torch.zeros_like(sig))
+    return ((Z / colnorm[:, None] if colnorm is not None else Z) * inv[None, :]).contiguous()
+
+
 def install(monkeypatch):
     from romtime_amd import ops
 
     for name in ("to_device", "to_device_index", "gram", "gram_scale", "gemm_tn", "gemm_nn", "rank_update", "deim_greedy",
-                 "csr_spmm", "project_csr", "project_csr_batched", "dense_solve"):
+                 "csr_spmm", "project_csr", "project_csr_batched", "dense_solve", "backproject_weights"):
         monkeypatch.setattr(ops, name, globals()[name])
