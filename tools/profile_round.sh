@@ -13,7 +13,7 @@ cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-secondary --no-latency"
 python3 $R/bench.py > $O/bench.log 2>&1 || exit 1
 tail -1 $O/bench.log > $DEST/${ROUND}_bench_${TAG}.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-secondary --no-latency > $O/stats.log 2>&1 || exit 2
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --no-cpu-baseline --no-secondary --no-latency > $O/stats.log 2>&1 || exit 2
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/fetch -- $B > $O/fetch.log 2>&1 || exit 3
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/write -- $B > $O/write.log 2>&1 || exit 4
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d $O/sq -- $B > $O/sq.log 2>&1 || exit 5
