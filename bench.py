@@ -200,7 +200,7 @@ def main():
                          "rocprofv3 so that the kernel statistics are those of the timed region's kernels only")
     ap.add_argument("--mode", choices=("auto", "pipeline", "latency"), default="auto",
                     help="pipeline: the steps run through PodPipeline (eigensolve of step i beside the Gram of step i+1 on "
-                         "CU-partitioned streams); latency: one pod_device call after the other; auto: pipeline up to 2 GPUs")
+                         "CU-partitioned streams); latency: one pod_device call after the other; auto = pipeline")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -243,7 +243,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    mode = args.mode if args.mode != "auto" else ("pipeline" if world <= 2 else "latency")
+    mode = args.mode if args.mode != "auto" else "pipeline"
     latency_ms = None
     if mode == "pipeline":
         # The K steps are K independent PODs (as the per-parameter PODs of a tree walk are): PodPipeline keeps two of

@@ -106,6 +106,15 @@ class PodPipeline:
         self.ctxE.set_option("eig_one_xcd", 0)       # the E CUs span all XCDs: write-through hand-off
         self.ctxG.set_option("cu_limit", 8 * g_count)
         self.group = group
+        # Row-sharded run: the Sturm multisection and the eigenvectors of the (replicated) tridiagonal form are split over
+        # the ranks and all-gathered on stream E, through a process group of their own so that these small collectives
+        # never queue behind the Gram all-reduce of the next snapshot set on stream G.
+        self.group_e = None
+        if group is not None:
+            import torch.distributed as dist
+
+            if dist.get_world_size(group) > 1:
+                self.group_e = dist.new_group(ranks=dist.get_process_group_ranks(group), backend=dist.get_backend(group))
         self.eig_cus = 8 * e
         self.recomputed = 0                          # sets that failed a check and took the regular route
         self.gram_kernel_ms = []                     # per set: Gram kernels + slab reduction, stream events on stream G
@@ -141,8 +150,25 @@ class PodPipeline:
             self.sE.wait_event(item["g"])
             G = item["G"]
             colnorm, flag = ops.gram_scale(G, normalize)
-            lam_d, status = ops.sym_eig_values(G)
-            Z = ops.sym_eig_vectors(lam_d, k)
+            if self.group_e is None:
+                lam_d, status = ops.sym_eig_values(G)
+                Z = ops.sym_eig_vectors(lam_d, k)
+            else:  # as pod._SmallEig: every rank tridiagonalises (bit-identical), searches / back-transforms its share
+                n = G.shape[0]
+                first, cnt = pod._share(n, self.group_e)
+                part, st_part = ops.sym_eig_values(G, first, cnt)
+                pieces = pod._allgather(torch.cat([part[first:first + cnt], st_part.to(torch.float64)]), self.group_e)
+                lam_d = torch.empty(n, dtype=torch.float64, device=G.device)
+                for r, piece in enumerate(pieces):
+                    f, _ = pod._share(n, self.group_e, rank=r)
+                    lam_d[f:f + cnt] = piece[:cnt]
+                status = torch.stack([piece[cnt] for piece in pieces]).max().reshape(1)
+                kf, kc = pod._share(k, self.group_e)
+                zs = pod._allgather(ops.sym_eig_vectors(lam_d, kc, first=kf), self.group_e)
+                Z = torch.empty((n, k), dtype=torch.float64, device=G.device)
+                for r, piece in enumerate(zs):
+                    f, _ = pod._share(k, self.group_e, rank=r)
+                    Z[:, f:f + kc] = piece
             item["Zs"] = ops.backproject_weights(Z, lam_d, colnorm if normalize else None)
             item["colnorm"], item["Z"] = colnorm, Z
             head = torch.cat([lam_d, status.to(torch.float64), flag.to(torch.float64), item["Gbuf"][-1:]])
