@@ -251,7 +251,11 @@ def main():
         # delivers its complete result (basis on the device, all singular values on the host) before the region ends.
         from romtime_amd.pipeline import PodPipeline
 
-        pipe = PodPipeline(group=group)
+        if world > torch.cuda.device_count():
+            # gloo rehearsal, ranks sharing a GPU: every rank's eigensolver team needs CUs of its own
+            pipe = PodPipeline(group=group, eig_first_cu=4 * local_rank, gram_range=(4 * world, 32 - 4 * world))
+        else:
+            pipe = PodPipeline(group=group)
         pipe.map([X] * max(args.warmup, 1), num=r, normalize=True)
         pipe.gram_kernel_ms.clear()
         barrier()
