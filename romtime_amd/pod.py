@@ -491,7 +491,15 @@ def orth(snapshots, num=None, tol=None, normalize=True, return_VT=False, passes=
 
     ndarray in -> ndarrays out ``(Q, s, energy[, VT])``; a float64 CUDA tensor in -> ``Q`` stays on
     the device (``s``, ``energy``, ``VT`` are small host arrays).  Columns of ``Q`` are defined up
-    to sign, as with any SVD.  ``passes`` (None = automatic, 1, 2) and ``group`` are extensions."""
+    to sign, as with any SVD.  ``passes`` (None = automatic, 1, 2) and ``group`` are extensions.
+
+    Which entries of ``s`` to trust.  ALL singular values are returned, as the reference does (its reports store
+    them, rom.py:338-340,386-388).  They come from Gram matrices, so an entry carries an ABSOLUTE error of about
+    eps sigma_L^2 / sigma_i, sigma_L being the largest singular value of the level that produced it: every kept
+    mode, and every mode the truncation rule had to look at, is resolved to dgesvd's accuracy (deflated levels restart
+    the scale at each level); entries further down the tail than that - below sqrt(eps) sigma_L of the last level and
+    not needed to decide the rank - are accurate to that absolute bound only (an exactly zero singular value can read
+    1e-8 sigma_1).  ``energy`` is insensitive to this (it sums sigma^2)."""
     if isinstance(snapshots, list):
         raise ValueError("You should use an array, not a list.")
     on_host = not isinstance(snapshots, torch.Tensor)

@@ -123,40 +123,17 @@ class PistonWorkflow:
 
     # ---- f2: artefacts and the resume flow (hrom.py:137-177 dump_*, :344-417 start_from_existing_basis) ------------
     def dump_artefacts(self):
-        from romtime_amd.conventions import OperatorType as OT
-        from romtime_amd.conventions import StorageNames
-        from romtime_amd.utils import dump_json, dump_pickle
+        from romtime_amd.artefacts import dump_offline
 
-        dump_json(StorageNames.MU_SPACE, self.rom.mu_space)
-        dump_pickle(StorageNames.ROM, self.rom.basis)
-        dump_pickle(StorageNames.SROM, self.srom.basis)
-        dump_pickle(f"basis_fom_n-mdeim_{OT.TRILINEAR}.pkl", self.srom.basis_nonlinear)
-        dump_pickle(StorageNames.VALIDATION_SOLUTIONS, self.validation_solutions)
+        dump_offline(self.rom, self.srom, self.validation_solutions)
 
-    def start_from_existing_basis(self, srom_keep=None, nmdeim_size=None):
-        from romtime_amd.conventions import OperatorType as OT
-        from romtime_amd.conventions import Stage, StorageNames
-        from romtime_amd.utils import read_json, read_pickle
+    def start_from_existing_basis(self):
+        from romtime_amd.artefacts import start_from_existing_basis
 
-        self.validation_solutions = read_pickle(StorageNames.VALIDATION_SOLUTIONS)
-        try:
-            mu_space = read_json(StorageNames.MU_SPACE)
-        except FileNotFoundError:
-            mu_space = {Stage.OFFLINE: [], Stage.ONLINE: [], Stage.VALIDATION: []}
-        basis_srom = read_pickle(StorageNames.SROM)
-        if srom_keep is not None:
-            basis_srom = basis_srom[:, :srom_keep]
-        self.srom.load_from_basis(basis=basis_srom, mu_space=mu_space)
-        self.rom = self.srom.truncate(wi.PISTON_SROM_TRUNCATE)
-        for red in (self.deim_rhs, self.mdeim_mass, self.mdeim_stiffness, self.mdeim_convection, self.mdeim_trilinear_lifting):
-            red.load_fom_basis()
-        self.mdeim_trilinear.load_fom_basis(keep=nmdeim_size)
-        pairs = zip((self.deim_rhs, self.mdeim_mass, self.mdeim_stiffness, self.mdeim_convection,
-                     self.mdeim_trilinear_lifting, self.mdeim_trilinear),
-                    (OT.LIFTING, OT.MASS, OT.STIFFNESS, OT.CONVECTION, OT.NONLINEAR_LIFTING, OT.TRILINEAR))
-        for red, which in pairs:
-            for rom in (self.rom, self.srom):
-                rom.add_hyper_reductor(reductor=red, which=which)
+        reductors = {k: getattr(self, k) for k in ("deim_rhs", "mdeim_mass", "mdeim_stiffness", "mdeim_convection",
+                                                   "mdeim_trilinear_lifting", "mdeim_trilinear")}
+        self.rom, self.validation_solutions = start_from_existing_basis(
+            self.srom, reductors, {"srom_truncate": wi.PISTON_SROM_TRUNCATE, "srom_num": None, "mdeim_truncate": None})
 
     def run(self):
         mus = [dict(m) for m in wi.PISTON_MUS]
