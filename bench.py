@@ -265,7 +265,6 @@ def main():
         elapsed = time.perf_counter() - t0
         out = dict(passes=outs[-1]["passes"])
         gram_ms = list(pipe.gram_kernel_ms)
-        gram_rows = float(np.mean(pipe.gram_rows))   # rows the timed Gram kernels covered (the rest ran on the eigensolver's CUs)
         stage_ms = dict(pipe.last_stage_ms, sets_recomputed_on_regular_route=float(pipe.recomputed),
                         eigensolver_cus=float(pipe.eig_cus))
         if world == 1 and not args.no_latency:   # one POD on its own (latency mode), for the record
@@ -315,9 +314,8 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         value = n_h * n * args.steps / elapsed
         k_ms = float(np.nanmean(gram_ms))
-        rows_k = gram_rows if mode == "pipeline" else n_local
-        alg_flops = rows_k * n * (n + 1)            # symmetric Gram: N n (n+1) flops
-        alg_bytes = 8 * (rows_k * n + n * n)        # read X once + write G
+        alg_flops = n_local * n * (n + 1)           # symmetric Gram: N n (n+1) flops
+        alg_bytes = 8 * (n_local * n + n * n)       # read X once + write G
         achieved = alg_flops / (k_ms * 1e-3) / 1e12
         # HBM bytes per Gram: NOT measured in this run - PMC counters need rocprofv3's own passes over this same
         # command; the committed summary of those passes is read and labelled as such
@@ -333,7 +331,7 @@ def main():
                                "of one Gram, one event pair around both launches"
                                + ("; in pipeline mode the pair is on the Gram's own CU-masked stream, includes the 0.03 ms "
                                   "slab reduction, and the kernels hold 224 of the 256 CUs)" if mode == "pipeline" else ")"),
-                        kernel_ms=k_ms, rows_per_launch=rows_k, frac_of_cu_share_peak=(achieved / FP64_MFMA_PEAK_TFLOPS * 256.0 / 224.0
+                        kernel_ms=k_ms, frac_of_cu_share_peak=(achieved / FP64_MFMA_PEAK_TFLOPS * 256.0 / 224.0
                                                                  if mode == "pipeline" else achieved / FP64_MFMA_PEAK_TFLOPS),
                         algorithmic_flops=alg_flops, algorithmic_bytes=alg_bytes,
                         hbm_frac=alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,

@@ -12,9 +12,8 @@ tools/probes/probe_cumask.hip).  Kernels of the two streams occupy disjoint CUs,
 order, and the persistent Gram grid is sized for its share ("cu_limit").  Each stream has its own rt_ctx (own scratch
 arenas).  Per snapshot set i:
 
-    G:  Gram_i of rows [0, (1 - f) N)                                                    (record g_i)
-    E:  Gram_i of rows [(1 - f) N, N);  wait g_i;  add [; all-reduce];  scale, tridiagonalise, eigenvalues,
-        k eigenvectors, D^-1 W S^-1                                                       (record e_i)
+    G:  Gram_i                               (record g_i)
+    E:  wait g_i;  scale, tridiagonalise, eigenvalues, k eigenvectors, D^-1 W S^-1      (record e_i)
     G:  Gram_{i+1};  wait e_i;  Q_i = X_i (D^-1 W S^-1)                                  (record b_i)
 
 so stream G runs  Gram_{i+1} | back-projection_i | Gram_{i+2} ...  without gaps while stream E works one set behind.
@@ -76,17 +75,14 @@ atexit.register(shutdown)
 
 
 class PodPipeline:
-    def __init__(self, eig_cus_per_xcd: int = 4, device=None, group=None, eig_first_cu: int = 0, gram_range=None,
-                 balance: bool = True):
+    def __init__(self, eig_cus_per_xcd: int = 4, device=None, group=None, eig_first_cu: int = 0, gram_range=None):
         """``eig_cus_per_xcd``: CUs of every XCD given to the eigensolver stream (4 -> 32 CUs: a CU per cooperating
         workgroup; 4 and 8 keep the shader engines of an XCD evenly loaded, other values measured slower).
         ``group``: torch.distributed process group of a row-sharded run - the Gram matrices are summed over it on stream
         G (one all-reduce per snapshot set), the small eigenproblem is replicated on every rank (identical inputs,
         deterministic kernels: identical outputs).
         ``eig_first_cu`` / ``gram_range`` = (first, count): explicit per-XCD CU ranges of the two streams, for processes that
-        share one GPU (their eigensolver teams must not share CUs: a team spins until all its workgroups are resident).
-        ``balance``: give the eigensolver's CUs the Gram of the last rows of every set, the share chosen from the event
-        timings of the sets already finished so that both streams take equally long."""
+        share one GPU (their eigensolver teams must not share CUs: a team spins until all its workgroups are resident)."""
         if not torch.cuda.is_available():
             raise _lib.RomtimeHipError("no MI355X visible: romtime_amd's hot path runs on the GPU only")
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
@@ -122,10 +118,6 @@ class PodPipeline:
         self.eig_cus = 8 * e
         self.recomputed = 0                          # sets that failed a check and took the regular route
         self.gram_kernel_ms = []                     # per set: Gram kernels + slab reduction, stream events on stream G
-        self.gram_rows = []                          # ... and the rows that Gram covered (the rest went to stream E)
-        self.gram_cus = 8 * g_count
-        self.balance = bool(balance)
-        self.share_e = 0.0                           # fraction of the rows whose Gram runs on the eigensolver's CUs
         self.last_stage_ms = {}
 
     def close(self):
@@ -134,49 +126,29 @@ class PodPipeline:
 
     # ---- stages ----------------------------------------------------------------------------------------------
     def _gram(self, item):
-        """Stream G: Gram of the first (1 - f) of the rows.  The eigensolver's CUs idle for about a third of every set;
-        they take the remaining rows (``_gram_tail``, on stream E right after the previous set's eigensolve) and the two
-        partial Gram matrices are added on stream E, which is where the sum is needed first."""
         X = item["X"]
         n = X.shape[1]
-        N = X.shape[0]
-        tail = int(self.share_e * N) // 1024 * 1024
-        if tail < 16384 or N - tail < 16384:
-            tail = 0
-        item["tail_rows"] = tail
         with self.ctxG.use(self.sG):
             item["t0"] = torch.cuda.Event(enable_timing=True)
             item["t0"].record()
             Gbuf = torch.empty(n * n + 1, dtype=torch.float64, device=X.device)   # G and the row count: one all-reduce
-            item["G"] = ops.gram(X[: N - tail] if tail else X, out=Gbuf[: n * n].view(n, n))
-            Gbuf[n * n:].fill_(float(N))
+            item["G"] = ops.gram(X, out=Gbuf[: n * n].view(n, n))
+            Gbuf[n * n:].fill_(float(X.shape[0]))
             item["k0"] = torch.cuda.Event(enable_timing=True)
             item["k0"].record()                                                    # Gram kernels + slab reduction end here
+            if self.group is not None:
+                import torch.distributed as dist
+
+                dist.all_reduce(Gbuf, op=dist.ReduceOp.SUM, group=self.group)
             item["Gbuf"] = Gbuf
-            item["g"] = item["k0"]
-        if tail:
-            with self.ctxE.use(self.sE):
-                item["te0"] = torch.cuda.Event(enable_timing=True)
-                item["te0"].record()
-                item["G_tail"] = ops.gram(X[N - tail:])
-                item["te1"] = torch.cuda.Event(enable_timing=True)
-                item["te1"].record()
+            item["g"] = torch.cuda.Event(enable_timing=True)
+            item["g"].record()
 
     def _eig(self, item):
         k, normalize = item["k"], item["normalize"]
         with self.ctxE.use(self.sE):
-            item["ee0"] = torch.cuda.Event(enable_timing=True)
-            item["ee0"].record()
             self.sE.wait_event(item["g"])
             G = item["G"]
-            if item["tail_rows"]:
-                G += item["G_tail"]
-            if self.group is not None:
-                import torch.distributed as dist
-
-                dist.all_reduce(item["Gbuf"], op=dist.ReduceOp.SUM, group=self.group)
-            item["ee1"] = torch.cuda.Event(enable_timing=True)
-            item["ee1"].record()                       # the Gram matrix of the whole (global) snapshot set is complete
             colnorm, flag = ops.gram_scale(G, normalize)
             if self.group_e is None:
                 lam_d, status = ops.sym_eig_values(G)
@@ -211,8 +183,6 @@ class PodPipeline:
         ctx, st = self.ctxG, self.sG
         with ctx.use(st):
             st.wait_event(item["e"])
-            item["b0"] = torch.cuda.Event(enable_timing=True)
-            item["b0"].record()
             item["Q"] = ops.gemm_nn(item["X"], item["Zs"])
             item["b"] = torch.cuda.Event(enable_timing=True)
             item["b"].record()
@@ -229,23 +199,11 @@ class PodPipeline:
         gaps = lam[:k] - lam[1:k + 1] if k < n else np.r_[lam[:k - 1] - lam[1:k], lam[k - 1]]
         ok = (status == 0 and s[0] > 0 and s[k - 1] >= pod.TWO_PASS_RATIO * s[0]
               and gaps.min() >= pod.RR_GAP * max(lam[0], 1e-300) and n_rows >= n)
-        d_gram = item["t0"].elapsed_time(item["k0"])
-        d_eig = item["ee1"].elapsed_time(item["e"])
-        d_back = item["b0"].elapsed_time(item["b"])
-        tail, N = item["tail_rows"], item["X"].shape[0]
-        d_tail = item["te0"].elapsed_time(item["te1"]) if tail else 0.0
-        self.last_stage_ms = dict(gram_kernel_ms=d_gram, gram_rows_on_eig_cus=float(tail), gram_tail_ms=d_tail,
-                                  eig_chain_ms=d_eig, backproject_ms=d_back,
+        self.last_stage_ms = dict(gram_kernel_ms=item["t0"].elapsed_time(item["k0"]),
+                                  gram_allreduce_ms=item["t0"].elapsed_time(item["g"]),
+                                  eig_chain_ms=item["g"].elapsed_time(item["e"]),
                                   gram_start_to_basis_ms=item["t0"].elapsed_time(item["b"]))
-        self.gram_kernel_ms.append(d_gram)
-        self.gram_rows.append(N - tail)
-        if self.balance and N >= 65536:
-            # Balance the two streams for the sets to come: stream G spends (1 - f) N / r_G + back-projection per set,
-            # stream E the eigensolve + f N / r_E; equal for f* below (rates from this set's own event timings).
-            r_g = (N - tail) / max(d_gram, 1e-6)
-            r_e = tail / d_tail if tail else r_g * self.eig_cus / max(self.gram_cus, 1) * 0.6
-            target = (N / r_g + d_back - d_eig) / (N / r_e + N / r_g)
-            self.share_e = float(min(max(0.5 * self.share_e + 0.5 * target, 0.0), 0.2))
+        self.gram_kernel_ms.append(self.last_stage_ms["gram_kernel_ms"])
         if not ok:
             # what pod_device decides after the fact too: this spectrum needs deflated levels / a Rayleigh-Ritz step
             self.recomputed += 1
