@@ -85,6 +85,18 @@ struct Panel {
     }
   }
 
+  // The same for KC == false with the address split the way the hardware wants it: a wave-uniform base (SGPR pair,
+  // advanced by scalar adds from stage to stage) plus ONE 32-bit per-thread byte offset that never changes
+  // (global_load_dwordx4 v, v_off, s[base]).  An FP64 MFMA blocks the VALU of its SIMD, so the 64-bit multiplies and
+  // adds of a per-stage address computation (about 20 VALU instructions per stage and wave) cost matrix-core time.
+  // voff = ((tid / (BT/2)) * ks + (tid % (BT/2)) * 2) * 8;  rows_step_bytes = (NTHR / (BT/2)) * ks * 8.
+  static __device__ __forceinline__ void load_full_u(d2 (&regs)[NL], const char* __restrict__ base, unsigned voff,
+                                                     long rows_step_bytes) {
+    static_assert(!KC, "scalar-base loader: tile axis contiguous");
+#pragma unroll
+    for (int j = 0; j < NL; ++j) regs[j] = *reinterpret_cast<const d2*>(base + j * rows_step_bytes + voff);
+  }
+
   static __device__ __forceinline__ void store(const d2 (&regs)[NL], double* s, int tid) {
 #pragma unroll
     for (int j = 0; j < NL; ++j) {

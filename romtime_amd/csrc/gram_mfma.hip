@@ -17,6 +17,7 @@
 // Output: per-(XCD, slot) 128x128 slabs, summed in a fixed order by gram_reduce_kernel
 // (bitwise reproducible; exactly symmetric G).
 #include <cstdlib>
+#include <type_traits>
 
 #include "gemm_panel.h"
 
@@ -57,7 +58,11 @@ __global__ __launch_bounds__(GT, 4) void gram128_kernel(const GramParams p) {
 
   const int tid = threadIdx.x;
   const int x = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int tm = p.slot_tm[slot], tn = p.slot_tn[slot], q0 = p.slot_q[slot], S = p.slot_S[slot];
+  // (a byte table in the kernel arguments indexed by a run-time slot is fetched with VECTOR loads: without the
+  // readfirstlane every quantity derived from these four - tile origin, K range, panel pointers - lives in VGPRs and
+  // all the "uniform" arithmetic of the loop is VALU work, which FP64 MFMAs cannot overlap with)
+  const int tm = __builtin_amdgcn_readfirstlane((int)p.slot_tm[slot]), tn = __builtin_amdgcn_readfirstlane((int)p.slot_tn[slot]),
+            q0 = __builtin_amdgcn_readfirstlane((int)p.slot_q[slot]), S = __builtin_amdgcn_readfirstlane((int)p.slot_S[slot]);
   const long m0 = (long)tm * BT, n0 = (long)tn * BT;
   const long kbeg = (long)x * p.kx;
   const long kend = (kbeg + p.kx < p.K) ? kbeg + p.kx : p.K;
@@ -101,21 +106,27 @@ __global__ __launch_bounds__(GT, 4) void gram128_kernel(const GramParams p) {
   }
   __syncthreads();
 
-  for (int st = 0; st < nstages; ++st) {
-    const double* cA = (st & 1) ? sA1 : sA0;
-    const double* cB = (st & 1) ? sB1 : sB0;
-    const bool more = (st + 1 < nstages) && !(p.flags & 4);  // flags & 4: timing experiment, no refills
-    if (more) {
-      const long k0 = kbeg + (long)(q0 + (st + 1) * S) * KB;
-      if (interior && k0 + KB <= kend) {
-        P::load_full(ra, p.X, p.ks, p.ms, k0, m0, tid);
-        if constexpr (!DIAG) P::load_full(rb, p.X, p.ks, p.ms, k0, n0, tid);
-      } else {
-        P::load(ra, p.X, p.ks, p.ms, k0, kend, m0, p.n, p.vec, tid);
-        if constexpr (!DIAG) P::load(rb, p.X, p.ks, p.ms, k0, kend, n0, p.n, p.vec, tid);
-      }
-    }
-    if (p.flags & 1) __builtin_amdgcn_s_setprio(1);
+  // scalar-base addressing of the refills (row-major snapshots, interior tiles): uniform pointers to the panel rows of
+  // the NEXT stage, advanced by scalar adds; one per-thread byte offset for every load of the kernel
+  [[maybe_unused]] const char* gA = nullptr;
+  [[maybe_unused]] const char* gB = nullptr;
+  [[maybe_unused]] unsigned voff = 0;
+  [[maybe_unused]] long rows_step = 0, stage_step = 0;
+  if constexpr (!KC) {
+    const long k1 = kbeg + (long)(q0 + S) * KB;   // first row of stage 1
+    gA = reinterpret_cast<const char*>(p.X + k1 * p.ks + m0);
+    gB = reinterpret_cast<const char*>(p.X + k1 * p.ks + n0);
+    voff = (unsigned)(((long)(tid / (BT / 2)) * p.ks + (tid % (BT / 2)) * 2) * 8);
+    rows_step = (long)(GT / (BT / 2)) * p.ks * 8;
+    stage_step = (long)S * KB * p.ks * 8;
+  }
+
+  // stages whose 16 rows lie fully inside the K range: all of them, or all but the last (32-bit scalar compares in the loop)
+  int n_full = nstages;
+  if (nstages > 0 && kbeg + (long)(q0 + (nstages - 1) * S) * KB + KB > kend) n_full = nstages - 1;
+  if (!interior) n_full = 0;
+
+  auto compute = [&](const double* cA, const double* cB) {
     if constexpr (DIAG) {
 #pragma unroll
       for (int k4 = 0; k4 < KB / 4; ++k4) {
@@ -142,6 +153,49 @@ __global__ __launch_bounds__(GT, 4) void gram128_kernel(const GramParams p) {
             acc[i * 2 + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], b[j], acc[i * 2 + j], 0, 0, 0);
       }
     }
+  };
+
+  int st = 0;
+  if constexpr (!KC) {
+    // Fast loop (row-major snapshots, interior tile): every stage here refills the other buffer from a stage that lies
+    // fully inside the K range, through the scalar-base loader; unrolled by two so that the buffer parity is a
+    // compile-time constant and buffer selection folds into the immediate offsets of the ds instructions.  Nothing of
+    // the general (predicated) loader is live in it.
+    auto fast_stage = [&](auto parity) {
+      constexpr int PAR = decltype(parity)::value;
+      P::load_full_u(ra, gA, voff, rows_step);
+      if constexpr (!DIAG) P::load_full_u(rb, gB, voff, rows_step);
+      if (p.flags & 1) __builtin_amdgcn_s_setprio(1);
+      compute(PAR ? sA1 : sA0, PAR ? sB1 : sB0);
+      if (p.flags & 1) __builtin_amdgcn_s_setprio(0);
+      gA += stage_step;
+      gB += stage_step;
+      P::store(ra, PAR ? sA0 : sA1, tid);
+      if constexpr (!DIAG) P::store(rb, PAR ? sB0 : sB1, tid);
+      __syncthreads();
+    };
+    if (!(p.flags & 4))
+      for (; st + 2 < n_full; st += 2) {
+        fast_stage(std::integral_constant<int, 0>{});
+        fast_stage(std::integral_constant<int, 1>{});
+      }
+  }
+  for (; st < nstages; ++st) {  // the remaining stages (all of them for column-major snapshots and edge tiles)
+    const double* cA = (st & 1) ? sA1 : sA0;
+    const double* cB = (st & 1) ? sB1 : sB0;
+    const bool more = (st + 1 < nstages) && !(p.flags & 4);  // flags & 4: timing experiment, no refills
+    if (more) {
+      const long k0 = kbeg + (long)(q0 + (st + 1) * S) * KB;
+      if (st + 1 < n_full) {
+        P::load_full(ra, p.X, p.ks, p.ms, k0, m0, tid);
+        if constexpr (!DIAG) P::load_full(rb, p.X, p.ks, p.ms, k0, n0, tid);
+      } else {
+        P::load(ra, p.X, p.ks, p.ms, k0, kend, m0, p.n, p.vec, tid);
+        if constexpr (!DIAG) P::load(rb, p.X, p.ks, p.ms, k0, kend, n0, p.n, p.vec, tid);
+      }
+    }
+    if (p.flags & 1) __builtin_amdgcn_s_setprio(1);
+    compute(cA, cB);
     if (p.flags & 1) __builtin_amdgcn_s_setprio(0);
     if (more) {
       P::store(ra, (st & 1) ? sA0 : sA1, tid);
