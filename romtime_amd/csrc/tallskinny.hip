@@ -8,6 +8,8 @@
 // multiplied), 4 waves x 16 rows, each wave all ceil(k/16) column tiles; 29 KB of LDS and <= 128 VGPRs leave room
 // for four workgroups per CU.  Measured 4.1 TB/s at 1e6 x 512 -> 40 (generic skinny tile: 3.8; 64-column stages
 // with two workgroups per CU: 3.8).
+#include <cstdlib>
+
 #include "common.h"
 
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -28,6 +30,7 @@ struct TsParams {
   double* Y;
   long N, ldx, ldt, ldy;
   int n, k;
+  int no_fast;   // ROMTIME_TS_FLAGS & 1: measurement switch, general refill path only
 };
 
 template <int NT>
@@ -98,7 +101,49 @@ __global__ __launch_bounds__(TS_THREADS, NT <= 4 ? 4 : 2) void tallskinny_kernel
   __syncthreads();
   const double* fa = sA + (16 * wid + l15) * TS_SA + l4;  // A operand: row 16 w + l15, k = 4 k4 + l4
   const double* fb = sT + l4 * KP + l15;                   // B operand: k = 4 k4 + l4, column 16 j + l15
-  for (int c0 = 0; c0 < p.n; c0 += TS_KS) {
+  int c0 = 0;
+  // Fast loop for workgroups whose 64 rows exist and whose stages are whole (n a multiple of 32, 16-byte aligned pairs):
+  // the refill addresses are a wave-uniform base, advanced by scalar adds, plus per-thread byte offsets computed once
+  // - the general `fetch` spends ~10 VALU instructions per load on 64-bit address arithmetic and predicates, and an FP64
+  // MFMA cannot overlap with VALU work of its SIMD (24 MFMAs per wave and stage here: the kernel was VALU-bound).
+  const bool fast = !p.no_fast && xvec && tvec && (row0 + TS_BM <= p.N) && (p.n % TS_KS == 0) && ((p.k & 1) == 0) &&
+                    ((long)TS_BM * p.ldx * 8 < (1L << 31)) && ((long)TS_KS * p.ldt * 8 < (1L << 31));
+  if (fast) {
+    const char* gx = reinterpret_cast<const char*>(p.X + row0 * p.ldx + TS_KS);   // stage 1 of this workgroup's rows
+    const char* gt = reinterpret_cast<const char*>(p.T + (long)TS_KS * p.ldt);
+    const unsigned xoff = (unsigned)(((long)(tid / (TS_KS / 2)) * p.ldx + 2 * (tid % (TS_KS / 2))) * 8);
+    const long xstep = (long)(TS_THREADS / (TS_KS / 2)) * p.ldx * 8;               // load i: 16 i rows further down
+    unsigned toff[TL];
+    bool tuse[TL];
+#pragma unroll
+    for (int i = 0; i < TL; ++i) {
+      const int q = tid + TS_THREADS * i, kk = q / (KP / 2), j = 2 * (q % (KP / 2));
+      toff[i] = (unsigned)(((long)kk * p.ldt + j) * 8);
+      tuse[i] = j + 1 < p.k;                                                        // padded columns stay zero
+      tr[i] = d2{0.0, 0.0};
+    }
+    const long tstage = (long)TS_KS * p.ldt * 8;
+    for (; c0 + TS_KS < p.n; c0 += TS_KS) {
+#pragma unroll
+      for (int i = 0; i < TS_XL; ++i) xr[i] = *reinterpret_cast<const d2*>(gx + i * xstep + xoff);
+#pragma unroll
+      for (int i = 0; i < TL; ++i)
+        if (tuse[i]) tr[i] = *reinterpret_cast<const d2*>(gt + toff[i]);
+#pragma unroll
+      for (int k4 = 0; k4 < TS_KS / 4; ++k4) {
+        const double a = fa[4 * k4];
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fb[4 * k4 * KP + 16 * j], acc[j], 0, 0, 0);
+      }
+      gx += TS_KS * 8;
+      gt += tstage;
+      __syncthreads();
+      commit();
+      __syncthreads();
+    }
+  }
+  for (; c0 < p.n; c0 += TS_KS) {
     const bool more = c0 + TS_KS < p.n;
     if (more) fetch(c0 + TS_KS);
 #pragma unroll
@@ -128,7 +173,8 @@ __global__ __launch_bounds__(TS_THREADS, NT <= 4 ? 4 : 2) void tallskinny_kernel
 int rt_tallskinny(rt_ctx* ctx, const double* X, int64_t ldx, const double* T, int64_t ldt, int64_t N, int64_t n,
                   int64_t k, double* Y, int64_t ldy) {
   if (k > 128 || n < 2 * TS_KS || N < 64L * ctx->num_cus) return RT_ERR_UNSUPPORTED;
-  TsParams p{X, T, Y, (long)N, (long)ldx, (long)ldt, (long)ldy, (int)n, (int)k};
+  static const int ts_flags = [] { const char* e = getenv("ROMTIME_TS_FLAGS"); return e ? atoi(e) : 0; }();
+  TsParams p{X, T, Y, (long)N, (long)ldx, (long)ldt, (long)ldy, (int)n, (int)k, ts_flags & 1};
   const unsigned grid = (unsigned)((N + TS_BM - 1) / TS_BM);
   const int nt = (int)((k + 15) / 16);
   if (ctx->profile) {
