@@ -285,6 +285,8 @@ int rt_gram128(rt_ctx* ctx, const double* X, int64_t ks, int64_t ms, int64_t K, 
   p.tiles1 = tiles1;
   const long other = kc ? ms : ks;
   p.vec = ((((uintptr_t)X) & 15) == 0 && (other % 2 == 0)) ? 1 : 0;
+  // the scalar-base loader keeps a 32-bit per-thread byte offset of up to 8 rows: beyond that, the predicated loader
+  if (!kc && (long)ks * 8 * 8 >= (1L << 31)) p.vec = 0;
   static const int env_flags = [] { const char* e = getenv("ROMTIME_GRAM_FLAGS"); return e ? atoi(e) : 1; }();
   p.flags = env_flags;
 
