@@ -245,17 +245,31 @@ def main():
 
     mode = args.mode if args.mode != "auto" else "pipeline"
     latency_ms = None
+    pipe, why_not = None, None
     if mode == "pipeline":
         # The K steps are K independent PODs (as the per-parameter PODs of a tree walk are): PodPipeline keeps two of
         # them in flight, the n x n eigensolve of one beside the Gram kernel of the next on disjoint CUs.  Every step
         # delivers its complete result (basis on the device, all singular values on the host) before the region ends.
         from romtime_amd.pipeline import PodPipeline
 
-        if world > torch.cuda.device_count():
-            # gloo rehearsal, ranks sharing a GPU: every rank's eigensolver team needs CUs of its own
-            pipe = PodPipeline(group=group, eig_first_cu=4 * local_rank, gram_range=(4 * world, 32 - 4 * world))
-        else:
-            pipe = PodPipeline(group=group)
+        try:
+            if world > torch.cuda.device_count():
+                # gloo rehearsal, ranks sharing a GPU: every rank's eigensolver team needs CUs of its own
+                pipe = PodPipeline(group=group, eig_first_cu=4 * local_rank, gram_range=(4 * world, 32 - 4 * world))
+            else:
+                pipe = PodPipeline(group=group)
+        except Exception as exc:  # noqa: BLE001  (a host that refuses CU-masked queues: one POD after the other instead)
+            if args.mode == "pipeline":
+                raise
+            why_not = repr(exc)
+        ok = torch.tensor([0.0 if pipe is None else 1.0], dtype=torch.float64, device=device)
+        if world > 1:
+            import torch.distributed as dist
+
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # every rank takes the same route
+        if float(ok.item()) == 0.0:
+            pipe, mode = None, f"latency (pipeline unavailable: {why_not})"
+    if pipe is not None:
         pipe.map([X] * max(args.warmup, 1), num=r, normalize=True)
         pipe.gram_kernel_ms.clear()
         barrier()
@@ -311,6 +325,7 @@ def main():
     elapsed = float(t.item())
 
     if rank == 0:
+        pipe_mode = mode == "pipeline"
         ms_per_step = 1e3 * elapsed / args.steps
         value = n_h * n * args.steps / elapsed
         k_ms = float(np.nanmean(gram_ms))
@@ -330,9 +345,9 @@ def main():
                         kernel="gram128_kernel<KC,false> + gram128_kernel<KC,true> (off-diagonal + diagonal tiles "
                                "of one Gram, one event pair around both launches"
                                + ("; in pipeline mode the pair is on the Gram's own CU-masked stream, includes the 0.03 ms "
-                                  "slab reduction, and the kernels hold 224 of the 256 CUs)" if mode == "pipeline" else ")"),
+                                  "slab reduction, and the kernels hold 224 of the 256 CUs)" if pipe_mode else ")"),
                         kernel_ms=k_ms, frac_of_cu_share_peak=(achieved / FP64_MFMA_PEAK_TFLOPS * 256.0 / 224.0
-                                                                 if mode == "pipeline" else achieved / FP64_MFMA_PEAK_TFLOPS),
+                                                                 if pipe_mode else achieved / FP64_MFMA_PEAK_TFLOPS),
                         algorithmic_flops=alg_flops, algorithmic_bytes=alg_bytes,
                         hbm_frac=alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         note="FP64 Gram at n=512 is 64 flop/B: matrix-core bound, not HBM bound")
