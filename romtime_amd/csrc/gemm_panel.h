@@ -89,10 +89,17 @@ struct Panel {
   // advanced by scalar adds from stage to stage) plus ONE 32-bit per-thread byte offset that never changes
   // (global_load_dwordx4 v, v_off, s[base]).  An FP64 MFMA blocks the VALU of its SIMD, so the 64-bit multiplies and
   // adds of a per-stage address computation (about 20 VALU instructions per stage and wave) cost matrix-core time.
-  // voff = ((tid / (BT/2)) * ks + (tid % (BT/2)) * 2) * 8;  rows_step_bytes = (NTHR / (BT/2)) * ks * 8.
+  //   KC == false:  voff = ((tid / (BT/2)) * ks + (tid % (BT/2)) * 2) * 8,  step = (NTHR / (BT/2)) * ks * 8  (rows)
+  //   KC == true :  voff = ((tid / (KB/2)) * ms + (tid % (KB/2)) * 2) * 8,  step = (NTHR / (KB/2)) * ms * 8  (tile columns)
+  static __device__ __forceinline__ unsigned lane_offset(long ks, long ms, int tid) {
+    return KC ? (unsigned)(((long)(tid / (KB / 2)) * ms + (tid % (KB / 2)) * 2) * 8)
+              : (unsigned)(((long)(tid / (BT / 2)) * ks + (tid % (BT / 2)) * 2) * 8);
+  }
+  static __device__ __forceinline__ long load_step(long ks, long ms) {
+    return KC ? (long)(NTHR / (KB / 2)) * ms * 8 : (long)(NTHR / (BT / 2)) * ks * 8;
+  }
   static __device__ __forceinline__ void load_full_u(d2 (&regs)[NL], const char* __restrict__ base, unsigned voff,
                                                      long rows_step_bytes) {
-    static_assert(!KC, "scalar-base loader: tile axis contiguous");
 #pragma unroll
     for (int j = 0; j < NL; ++j) regs[j] = *reinterpret_cast<const d2*>(base + j * rows_step_bytes + voff);
   }

@@ -106,20 +106,13 @@ __global__ __launch_bounds__(GT, 4) void gram128_kernel(const GramParams p) {
   }
   __syncthreads();
 
-  // scalar-base addressing of the refills (row-major snapshots, interior tiles): uniform pointers to the panel rows of
+  // scalar-base addressing of the refills (interior tiles): uniform pointers to the panel rows of
   // the NEXT stage, advanced by scalar adds; one per-thread byte offset for every load of the kernel
-  [[maybe_unused]] const char* gA = nullptr;
-  [[maybe_unused]] const char* gB = nullptr;
-  [[maybe_unused]] unsigned voff = 0;
-  [[maybe_unused]] long rows_step = 0, stage_step = 0;
-  if constexpr (!KC) {
-    const long k1 = kbeg + (long)(q0 + S) * KB;   // first row of stage 1
-    gA = reinterpret_cast<const char*>(p.X + k1 * p.ks + m0);
-    gB = reinterpret_cast<const char*>(p.X + k1 * p.ks + n0);
-    voff = (unsigned)(((long)(tid / (BT / 2)) * p.ks + (tid % (BT / 2)) * 2) * 8);
-    rows_step = (long)(GT / (BT / 2)) * p.ks * 8;
-    stage_step = (long)S * KB * p.ks * 8;
-  }
+  const long k1 = kbeg + (long)(q0 + S) * KB;   // first row of stage 1
+  const char* gA = reinterpret_cast<const char*>(p.X + k1 * p.ks + m0 * p.ms);
+  const char* gB = reinterpret_cast<const char*>(p.X + k1 * p.ks + n0 * p.ms);
+  const unsigned voff = P::lane_offset(p.ks, p.ms, tid);
+  const long rows_step = P::load_step(p.ks, p.ms), stage_step = (long)S * KB * p.ks * 8;
 
   // stages whose 16 rows lie fully inside the K range: all of them, or all but the last (32-bit scalar compares in the loop)
   int n_full = nstages;
@@ -156,8 +149,8 @@ __global__ __launch_bounds__(GT, 4) void gram128_kernel(const GramParams p) {
   };
 
   int st = 0;
-  if constexpr (!KC) {
-    // Fast loop (row-major snapshots, interior tile): every stage here refills the other buffer from a stage that lies
+  {
+    // Fast loop (interior tile, either memory order): every stage here refills the other buffer from a stage that lies
     // fully inside the K range, through the scalar-base loader; unrolled by two so that the buffer parity is a
     // compile-time constant and buffer selection folds into the immediate offsets of the ds instructions.  Nothing of
     // the general (predicated) loader is live in it.
@@ -286,7 +279,7 @@ int rt_gram128(rt_ctx* ctx, const double* X, int64_t ks, int64_t ms, int64_t K, 
   const long other = kc ? ms : ks;
   p.vec = ((((uintptr_t)X) & 15) == 0 && (other % 2 == 0)) ? 1 : 0;
   // the scalar-base loader keeps a 32-bit per-thread byte offset of up to 8 rows: beyond that, the predicated loader
-  if (!kc && (long)ks * 8 * 8 >= (1L << 31)) p.vec = 0;
+  if ((!kc && (long)ks * 8 * 8 >= (1L << 31)) || (kc && (long)ms * 64 * 8 >= (1L << 31))) p.vec = 0;
   static const int env_flags = [] { const char* e = getenv("ROMTIME_GRAM_FLAGS"); return e ? atoi(e) : 1; }();
   p.flags = env_flags;
 
