@@ -12,8 +12,9 @@ tools/probes/probe_cumask.hip).  Kernels of the two streams occupy disjoint CUs,
 order, and the persistent Gram grid is sized for its share ("cu_limit").  Each stream has its own rt_ctx (own scratch
 arenas).  Per snapshot set i:
 
-    G:  Gram_i                               (record g_i)
+    G:  Gram_i  [all-reduce over the row slabs]                                         (record g_i)
     E:  wait g_i;  scale, tridiagonalise, eigenvalues, k eigenvectors, D^-1 W S^-1      (record e_i)
+        [row-sharded: on rank i mod P only; its results are broadcast on a third stream]
     G:  Gram_{i+1};  wait e_i;  Q_i = X_i (D^-1 W S^-1)                                  (record b_i)
 
 so stream G runs  Gram_{i+1} | back-projection_i | Gram_{i+2} ...  without gaps while stream E works one set behind.
@@ -106,15 +107,17 @@ class PodPipeline:
         self.ctxE.set_option("eig_one_xcd", 0)       # the E CUs span all XCDs: write-through hand-off
         self.ctxG.set_option("cu_limit", 8 * g_count)
         self.group = group
-        # Row-sharded run: the Sturm multisection and the eigenvectors of the (replicated) tridiagonal form are split over
-        # the ranks and all-gathered on stream E, through a process group of their own so that these small collectives
-        # never queue behind the Gram all-reduce of the next snapshot set on stream G.
-        self.group_e = None
+        # Row-sharded run: the small collectives of stream E (the broadcast of a set's eigen-results from the rank that
+        # solved it) go through a process group of their own, so that they never queue behind the Gram all-reduce of the
+        # next snapshot set on stream G.
+        self.group_e, self.world, self.rank = None, 1, 0
         if group is not None:
             import torch.distributed as dist
 
             if dist.get_world_size(group) > 1:
                 self.group_e = dist.new_group(ranks=dist.get_process_group_ranks(group), backend=dist.get_backend(group))
+                self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.sC = torch.cuda.Stream(self.device) if self.group_e is not None else None   # broadcasts of eigen-results
         self.eig_cus = 8 * e
         self.recomputed = 0                          # sets that failed a check and took the regular route
         self.gram_kernel_ms = []                     # per set: Gram kernels + slab reduction, stream events on stream G
@@ -145,36 +148,51 @@ class PodPipeline:
             item["g"].record()
 
     def _eig(self, item):
+        """Stream E: the n x n eigenproblem of this set - on every rank of a single-GPU run, on ONE rank (set index mod
+        P) of a row-sharded run.  After the all-reduce every rank holds the same G and the sets are independent, so the
+        ranks take turns: each rank's eigensolver stream carries 1/P of the sets and the replicated, latency-bound
+        tridiagonalisation stops being the Amdahl term of a sequence of PODs (it still is for a single POD:
+        pod.pod_device can only split the multisection).  Enqueued right behind the set's Gram, so that every rank has
+        its own eigenproblems under way before anybody waits for anybody else's results."""
         k, normalize = item["k"], item["normalize"]
+        item["owner"] = item["index"] % self.world
+        if self.rank != item["owner"]:
+            return
         with self.ctxE.use(self.sE):
             self.sE.wait_event(item["g"])
             G = item["G"]
+            n = G.shape[0]
             colnorm, flag = ops.gram_scale(G, normalize)
-            if self.group_e is None:
-                lam_d, status = ops.sym_eig_values(G)
-                Z = ops.sym_eig_vectors(lam_d, k)
-            else:  # as pod._SmallEig: every rank tridiagonalises (bit-identical), searches / back-transforms its share
-                n = G.shape[0]
-                first, cnt = pod._share(n, self.group_e)
-                part, st_part = ops.sym_eig_values(G, first, cnt)
-                pieces = pod._allgather(torch.cat([part[first:first + cnt], st_part.to(torch.float64)]), self.group_e)
-                lam_d = torch.empty(n, dtype=torch.float64, device=G.device)
-                for r, piece in enumerate(pieces):
-                    f, _ = pod._share(n, self.group_e, rank=r)
-                    lam_d[f:f + cnt] = piece[:cnt]
-                status = torch.stack([piece[cnt] for piece in pieces]).max().reshape(1)
-                kf, kc = pod._share(k, self.group_e)
-                zs = pod._allgather(ops.sym_eig_vectors(lam_d, kc, first=kf), self.group_e)
-                Z = torch.empty((n, k), dtype=torch.float64, device=G.device)
-                for r, piece in enumerate(zs):
-                    f, _ = pod._share(k, self.group_e, rank=r)
-                    Z[:, f:f + kc] = piece
-            item["Zs"] = ops.backproject_weights(Z, lam_d, colnorm if normalize else None)
-            item["colnorm"], item["Z"] = colnorm, Z
-            head = torch.cat([lam_d, status.to(torch.float64), flag.to(torch.float64), item["Gbuf"][-1:]])
+            lam_d, status = ops.sym_eig_values(G)
+            Z = ops.sym_eig_vectors(lam_d, k)
+            Zs = ops.backproject_weights(Z, lam_d, colnorm if normalize else None)
+            # eigenvalues | column norms | hand-off status | zero-norm flag | D^-1 W S^-1: what the other ranks need
+            item["payload"] = torch.cat([lam_d, colnorm, status.to(torch.float64), flag.to(torch.float64), Zs.reshape(-1)])
+            item["_keep"] = (lam_d, status, flag, Z, Zs, colnorm)
+            item["ec"] = torch.cuda.Event(enable_timing=True)
+            item["ec"].record()
+
+    def _share(self, item):
+        """The set's eigen-results on every rank: a broadcast from the rank that solved it (stream C, its own process
+        group), then the host copy of the spectrum."""
+        n, k = item["G"].shape[0], item["k"]
+        st = self.sE if self.group_e is None else self.sC
+        with torch.cuda.stream(st):
+            if self.group_e is not None:
+                import torch.distributed as dist
+
+                if self.rank == item["owner"]:
+                    st.wait_event(item["ec"])
+                else:
+                    item["payload"] = torch.empty(n * (k + 2) + 2, dtype=torch.float64, device=item["G"].device)
+                dist.broadcast(item["payload"], src=dist.get_global_rank(self.group_e, item["owner"]), group=self.group_e)
+            payload = item["payload"]
+            item["colnorm"] = payload[n:2 * n]
+            item["Zs"] = payload[2 * n + 2:].view(n, k)
+            head = torch.cat([payload[:n], payload[2 * n:2 * n + 2], item["Gbuf"][-1:]])
             item["head"] = torch.empty(head.numel(), dtype=torch.float64).pin_memory()
             item["head"].copy_(head, non_blocking=True)
-            item["_keep"] = (lam_d, status, flag, head)
+            item["_keep2"] = head
             item["e"] = torch.cuda.Event(enable_timing=True)
             item["e"].record()
 
@@ -221,8 +239,12 @@ class PodPipeline:
         ready.record(main)                       # the snapshot sets were produced on the caller's stream
         self.sG.wait_event(ready)
         self.sE.wait_event(ready)
+        if self.sC is not None:
+            self.sC.wait_event(ready)
         flight = collections.deque()
         it = iter(snapshot_sets)
+        self._admitted = 0
+        depth = max(depth, self.world + 1)       # enough sets in flight for every rank's eigensolver stream to have one
 
         def admit():
             try:
@@ -231,18 +253,27 @@ class PodPipeline:
                 return None
             if X.dim() != 2 or not X.is_cuda or X.dtype != torch.float64:
                 raise _lib.RomtimeHipError("PodPipeline takes 2-D float64 CUDA tensors")
-            item = dict(X=X, num=num, k=int(min(num, X.shape[1])), normalize=bool(normalize))
+            item = dict(X=X, num=num, k=int(min(num, X.shape[1])), normalize=bool(normalize), index=self._admitted)
+            self._admitted += 1
             self._gram(item)
+            self._eig(item)
             return item
 
-        nxt = admit()
-        while nxt is not None:
-            cur = nxt
-            self._eig(cur)
-            nxt = admit()                        # Gram of the next set goes onto stream G BEFORE this set's back-projection
+        pending = collections.deque()
+        for _ in range(self.world):               # Grams (and, on their owners, eigensolves) of the first P sets
+            item = admit()
+            if item is None:
+                break
+            pending.append(item)
+        while pending:
+            cur = pending.popleft()
+            self._share(cur)
+            nxt = admit()                         # the Gram of a later set goes onto stream G BEFORE this set's back-projection
+            if nxt is not None:
+                pending.append(nxt)
             self._backproject(cur)
             flight.append(cur)
-            while len(flight) > depth or (nxt is None and flight):
+            while len(flight) > depth or (not pending and flight):
                 yield self._finish(flight.popleft())
         done = torch.cuda.Event()
         done.record(self.sG)
@@ -250,6 +281,10 @@ class PodPipeline:
         done2 = torch.cuda.Event()
         done2.record(self.sE)
         main.wait_event(done2)
+        if self.sC is not None:
+            done3 = torch.cuda.Event()
+            done3.record(self.sC)
+            main.wait_event(done3)
 
     def map(self, snapshot_sets, num, normalize=True, depth=2):
         return list(self.run(snapshot_sets, num, normalize=normalize, depth=depth))
