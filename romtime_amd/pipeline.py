@@ -206,6 +206,9 @@ class PodPipeline:
             item["b"].record()
 
     def _finish(self, item):
+        if item["direct"]:
+            self.recomputed += 1
+            return pod.pod_device(item["X"], num=item["num"], normalize=item["normalize"], group=self.group)
         item["b"].synchronize()
         n, k = item["X"].shape[1], item["k"]
         head = item["head"].numpy()
@@ -255,8 +258,13 @@ class PodPipeline:
                 raise _lib.RomtimeHipError("PodPipeline takes 2-D float64 CUDA tensors")
             item = dict(X=X, num=num, k=int(min(num, X.shape[1])), normalize=bool(normalize), index=self._admitted)
             self._admitted += 1
-            self._gram(item)
-            self._eig(item)
+            n = X.shape[1]
+            # what the eigensolver's CU share cannot hold (the 128-workgroup team of n > 512) or the device eigensolver
+            # does not take (n < 3) goes the regular route when its turn comes; the order of the results is kept
+            item["direct"] = not (3 <= n <= 512)
+            if not item["direct"]:
+                self._gram(item)
+                self._eig(item)
             return item
 
         pending = collections.deque()
@@ -267,11 +275,13 @@ class PodPipeline:
             pending.append(item)
         while pending:
             cur = pending.popleft()
-            self._share(cur)
+            if not cur["direct"]:
+                self._share(cur)
             nxt = admit()                         # the Gram of a later set goes onto stream G BEFORE this set's back-projection
             if nxt is not None:
                 pending.append(nxt)
-            self._backproject(cur)
+            if not cur["direct"]:
+                self._backproject(cur)
             flight.append(cur)
             while len(flight) > depth or (not pending and flight):
                 yield self._finish(flight.popleft())

@@ -32,11 +32,12 @@ def test_pipeline_matches_single_pods_and_oracle():
     rng = np.random.RandomState(7)
     k = 6
     mats = [_matrix(rng, 9000, 96, 1.5), _matrix(rng, 20000, 130, 2.0), _matrix(rng, 9000, 96, 60.0),   # deep: regular route
-            np.asfortranarray(_matrix(rng, 7001, 200, 1.0)), _matrix(rng, 4096, 512, 3.0), _matrix(rng, 9000, 96, 1.5) * 7.0]
+            np.asfortranarray(_matrix(rng, 7001, 200, 1.0)), _matrix(rng, 4096, 512, 3.0), _matrix(rng, 9000, 96, 1.5) * 7.0,
+            _matrix(rng, 3000, 600, 2.0)]                                                                   # n > 512: regular route
     dev = [ops.to_device(m) for m in mats]
     pipe = PodPipeline()
     outs = pipe.map(dev, num=k, normalize=True)
-    assert len(outs) == len(mats) and pipe.recomputed == 1
+    assert len(outs) == len(mats) and pipe.recomputed == 2
     for X, Xd, out in zip(mats, dev, outs):
         single = pod.pod_device(Xd, num=k, normalize=True)
         assert out["r"] == single["r"] == k and out["passes"] == single["passes"]
