@@ -22,7 +22,6 @@ constexpr int TS_BM = 64;      // rows per workgroup
 constexpr int TS_KS = 32;      // contraction columns per stage
 constexpr int TS_SA = 34;      // LDS stride of the X stage ([row][k]): 2 SA == 4 (mod 8) -> the 16 rows of an
                                // A-operand read fall in distinct banks
-constexpr int TS_XL = TS_BM * TS_KS / 2 / TS_THREADS;  // d2 loads of X per thread and stage
 
 struct TsParams {
   const double* X;
@@ -33,8 +32,12 @@ struct TsParams {
   int no_fast;   // ROMTIME_TS_FLAGS & 1: measurement switch, general refill path only
 };
 
-template <int NT>
-__global__ __launch_bounds__(TS_THREADS, NT <= 4 ? 4 : 2) void tallskinny_kernel(const TsParams p) {
+// RB = 16-row blocks per wave: a workgroup takes 64 RB rows.  With RB = 2 a T stage (re-read from L2 by every workgroup)
+// serves twice as many rows: L2 -> CU traffic per row of X drops from 1.75x to 1.37x of the X bytes at k = 40.
+template <int NT, int RB>
+__global__ __launch_bounds__(TS_THREADS, RB == 2 ? (NT <= 4 ? 3 : 1) : (NT <= 4 ? 4 : 2)) void tallskinny_kernel(const TsParams p) {
+  constexpr int TS_BM = 64 * RB;
+  constexpr int TS_XL = TS_BM * TS_KS / 2 / TS_THREADS;      // d2 loads of X per thread and stage
   constexpr int KP = 16 * NT;                                 // padded output width
   constexpr int TL = (TS_KS * KP / 2 + TS_THREADS - 1) / TS_THREADS;  // d2 loads of T per thread and stage
   __shared__ __attribute__((aligned(16))) double sA[TS_BM * TS_SA];
@@ -45,9 +48,11 @@ __global__ __launch_bounds__(TS_THREADS, NT <= 4 ? 4 : 2) void tallskinny_kernel
   const bool xvec = ((p.ldx & 1) == 0) && ((reinterpret_cast<size_t>(p.X) & 15) == 0);
   const bool tvec = ((p.ldt & 1) == 0) && ((reinterpret_cast<size_t>(p.T) & 15) == 0);
 
-  d4 acc[NT];
+  d4 acc[RB][NT];
 #pragma unroll
-  for (int j = 0; j < NT; ++j) acc[j] = d4{0.0, 0.0, 0.0, 0.0};
+  for (int b = 0; b < RB; ++b)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[b][j] = d4{0.0, 0.0, 0.0, 0.0};
 
   d2 xr[TS_XL], tr[TL];
   auto fetch = [&](int c0) {  // stage of contraction columns c0 .. c0 + TS_KS - 1 into registers
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(TS_THREADS, NT <= 4 ? 4 : 2) void tallskinny_kernel
   fetch(0);
   commit();
   __syncthreads();
-  const double* fa = sA + (16 * wid + l15) * TS_SA + l4;  // A operand: row 16 w + l15, k = 4 k4 + l4
+  const double* fa = sA + (16 * wid + l15) * TS_SA + l4;  // A operand: row 16 (w + 4 b) + l15, k = 4 k4 + l4
   const double* fb = sT + l4 * KP + l15;                   // B operand: k = 4 k4 + l4, column 16 j + l15
   int c0 = 0;
   // Fast loop for workgroups whose 64 rows exist and whose stages are whole (n a multiple of 32, 16-byte aligned pairs):
@@ -131,10 +136,15 @@ __global__ __launch_bounds__(TS_THREADS, NT <= 4 ? 4 : 2) void tallskinny_kernel
         if (tuse[i]) tr[i] = *reinterpret_cast<const d2*>(gt + toff[i]);
 #pragma unroll
       for (int k4 = 0; k4 < TS_KS / 4; ++k4) {
-        const double a = fa[4 * k4];
+        double bq[NT];
 #pragma unroll
-        for (int j = 0; j < NT; ++j)
-          acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fb[4 * k4 * KP + 16 * j], acc[j], 0, 0, 0);
+        for (int j = 0; j < NT; ++j) bq[j] = fb[4 * k4 * KP + 16 * j];
+#pragma unroll
+        for (int b = 0; b < RB; ++b) {
+          const double a = fa[64 * b * TS_SA + 4 * k4];
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[b][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq[j], acc[b][j], 0, 0, 0);
+        }
       }
       gx += TS_KS * 8;
       gt += tstage;
@@ -148,23 +158,30 @@ __global__ __launch_bounds__(TS_THREADS, NT <= 4 ? 4 : 2) void tallskinny_kernel
     if (more) fetch(c0 + TS_KS);
 #pragma unroll
     for (int k4 = 0; k4 < TS_KS / 4; ++k4) {
-      const double a = fa[4 * k4];
+      double bq[NT];
 #pragma unroll
-      for (int j = 0; j < NT; ++j)
-        acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, fb[4 * k4 * KP + 16 * j], acc[j], 0, 0, 0);
+      for (int j = 0; j < NT; ++j) bq[j] = fb[4 * k4 * KP + 16 * j];
+#pragma unroll
+      for (int b = 0; b < RB; ++b) {
+        const double a = fa[64 * b * TS_SA + 4 * k4];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[b][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bq[j], acc[b][j], 0, 0, 0);
+      }
     }
     __syncthreads();
     if (more) commit();
     __syncthreads();
   }
 #pragma unroll
-  for (int j = 0; j < NT; ++j)
+  for (int b = 0; b < RB; ++b)
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const long row = row0 + 16 * wid + l4 + 4 * c;
-      const int col = 16 * j + l15;
-      if (row < p.N && col < p.k) p.Y[row * p.ldy + col] = acc[j][c];
-    }
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const long row = row0 + 64 * b + 16 * wid + l4 + 4 * c;
+        const int col = 16 * j + l15;
+        if (row < p.N && col < p.k) p.Y[row * p.ldy + col] = acc[b][j][c];
+      }
 }
 
 }  // namespace
@@ -175,8 +192,11 @@ int rt_tallskinny(rt_ctx* ctx, const double* X, int64_t ldx, const double* T, in
   if (k > 128 || n < 2 * TS_KS || N < 64L * ctx->num_cus) return RT_ERR_UNSUPPORTED;
   static const int ts_flags = [] { const char* e = getenv("ROMTIME_TS_FLAGS"); return e ? atoi(e) : 0; }();
   TsParams p{X, T, Y, (long)N, (long)ldx, (long)ldt, (long)ldy, (int)n, (int)k, ts_flags & 1};
-  const unsigned grid = (unsigned)((N + TS_BM - 1) / TS_BM);
   const int nt = (int)((k + 15) / 16);
+  // two 16-row blocks per wave when the 128-row workgroups still fill the chip a few times over and the accumulators fit
+  const int rb = (nt <= 4 && !(ts_flags & 2) && N >= 128L * 4 * ctx->num_cus) ? 2 : 1;
+  const int bm = 64 * rb;
+  const unsigned grid = (unsigned)((N + bm - 1) / bm);
   if (ctx->profile) {
     if (!ctx->ev0) {
       RT_HIP_CHECK(ctx, hipEventCreate(&ctx->ev0));
@@ -184,21 +204,25 @@ int rt_tallskinny(rt_ctx* ctx, const double* X, int64_t ldx, const double* T, in
     }
     RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   }
+#define TS_LAUNCH(NT_)                                                                                                  \
+  if (rb == 2) hipLaunchKernelGGL((tallskinny_kernel<(NT_ <= 4 ? NT_ : 4), 2>), dim3(grid), dim3(TS_THREADS), 0, ctx->stream, p); \
+  else hipLaunchKernelGGL((tallskinny_kernel<NT_, 1>), dim3(grid), dim3(TS_THREADS), 0, ctx->stream, p)
   switch (nt) {
-    case 1: hipLaunchKernelGGL(tallskinny_kernel<1>, dim3(grid), dim3(TS_THREADS), 0, ctx->stream, p); break;
-    case 2: hipLaunchKernelGGL(tallskinny_kernel<2>, dim3(grid), dim3(TS_THREADS), 0, ctx->stream, p); break;
-    case 3: hipLaunchKernelGGL(tallskinny_kernel<3>, dim3(grid), dim3(TS_THREADS), 0, ctx->stream, p); break;
-    case 4: hipLaunchKernelGGL(tallskinny_kernel<4>, dim3(grid), dim3(TS_THREADS), 0, ctx->stream, p); break;
-    case 5: hipLaunchKernelGGL(tallskinny_kernel<5>, dim3(grid), dim3(TS_THREADS), 0, ctx->stream, p); break;
-    case 6: hipLaunchKernelGGL(tallskinny_kernel<6>, dim3(grid), dim3(TS_THREADS), 0, ctx->stream, p); break;
-    case 7: hipLaunchKernelGGL(tallskinny_kernel<7>, dim3(grid), dim3(TS_THREADS), 0, ctx->stream, p); break;
-    default: hipLaunchKernelGGL(tallskinny_kernel<8>, dim3(grid), dim3(TS_THREADS), 0, ctx->stream, p); break;
+    case 1: TS_LAUNCH(1); break;
+    case 2: TS_LAUNCH(2); break;
+    case 3: TS_LAUNCH(3); break;
+    case 4: TS_LAUNCH(4); break;
+    case 5: TS_LAUNCH(5); break;
+    case 6: TS_LAUNCH(6); break;
+    case 7: TS_LAUNCH(7); break;
+    default: TS_LAUNCH(8); break;
   }
+#undef TS_LAUNCH
   RT_HIP_CHECK(ctx, hipGetLastError());
   if (ctx->profile) {
     RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     ctx->ev_valid = true;
   }
-  ctx->last_grid = grid; ctx->last_splits = 1; ctx->last_tile = TS_BM * 1000 + 16 * nt;
+  ctx->last_grid = grid; ctx->last_splits = 1; ctx->last_tile = bm * 1000 + 16 * nt;
   return RT_OK;
 }
