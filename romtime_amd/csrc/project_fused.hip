@@ -23,9 +23,22 @@
 #include "common.h"
 
 #include <cstdlib>
+#include <type_traits>
+
+// Timing-only builds (-DROMTIME_PF_ABLATE, then ROMTIME_PF_FLAGS = 8: no buffer-descriptor fetch, 16: no gather,
+// 32: no MFMAs, 64: no global loads) price the phases of a stage; their results are wrong by design, so the
+// switches do not exist in the shipped library.  Measured (32 vectors, N = 1e5, r = 80, ms): all 0.98 = skeleton
+// (barriers, commit, scalar code) 0.19 + MFMAs 0.57 + gather 0.17 + fetch 0.07 - the phases of the two workgroups
+// a CU holds add up rather than overlap; one workgroup per CU takes 1.39.
+#ifdef ROMTIME_PF_ABLATE
+#define PF_ABLATE(bit) ((p.flags & (bit)) != 0)
+#else
+#define PF_ABLATE(bit) false
+#endif
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -35,23 +48,31 @@ constexpr int RMAX = 128;
 constexpr int WROWS = 48;     // V rows kept in LDS per stage (banded FE operators touch ~PK + 2*bandwidth)
 constexpr int EMAX = PT;      // entries of one stage staged through LDS (one per thread)
 
-// == 16 (mod 32) doubles: conflict-free ds_read_b64 of the MFMA operands
-__host__ __device__ constexpr int stride_of(int tr) { return ((16 * tr + 31) / 32) * 32 + 16; }
+// == 16 (mod 32) doubles: conflict-free ds_read_b64 of the MFMA operands (16 tr already is for odd tr)
+__host__ __device__ constexpr int stride_of(int tr) { return 16 * tr + ((tr & 1) ? 0 : 16); }
 
-// Everything a stage needs to start its loads, in one wave-uniform 32-byte record (one scalar load, issued a
-// whole stage ahead): entry range [e0, e1) of the stage's rows and their column window [lo, hi];
-// hi = -1 marks "do not window" (too wide / too many entries).
+// Everything a stage needs to start its loads, in one wave-uniform 16-byte record (one scalar load, issued a
+// whole stage ahead): first entry e0 of the stage's rows, first row `lo` of their column window, and packed
+//   bits  0..9   ne    entries of the stage (<= EMAX)
+//   bits 10..16  nrow  rows of the window (<= WROWS); 0 = do not window (too wide / too many entries)
+//   bits 17..26  mr    most entries in one row of the stage
+//   bit  27      uni   every row of the stage has exactly mr entries
 struct StageRec {
-  long e0, e1;
-  int lo, hi;
-  int pad0, pad1;
+  long e0;
+  int lo;
+  unsigned packed;
 };
+__host__ __device__ inline int rec_ne(unsigned pk) { return (int)(pk & 1023u); }
+__host__ __device__ inline int rec_nrow(unsigned pk) { return (int)((pk >> 10) & 127u); }
+__host__ __device__ inline int rec_mr(unsigned pk) { return (int)((pk >> 17) & 1023u); }
+__host__ __device__ inline bool rec_uni(unsigned pk) { return ((pk >> 27) & 1u) != 0; }
 
 struct Entry {  // staged entry: value and byte offset of its V row inside the LDS window
   double val;
   int rowoff;
   int pad;
 };
+constexpr int EPAD = 8;       // zero entries behind the staged ones (a gather chunk may read past the last entry)
 
 struct ProjParams {
   const long* indptr;
@@ -61,8 +82,9 @@ struct ProjParams {
   const double* V;
   long ldv;
   double* slab;        // [B][S][r*r]
-  long N, k_per_split;
+  int N, k_per_split;
   int r, B, S;
+  int flags;
   const StageRec* rec;  // [stages]
 };
 
@@ -79,40 +101,44 @@ __global__ void project_stages_kernel(const long* __restrict__ indptr, const lon
     lo = min(lo, c);
     hi = max(hi, c);
   }
+  long mr = 0, mn = 1L << 40;
+  for (long k = k0; k < k1; ++k) {
+    const long c = indptr[k + 1] - indptr[k];
+    mr = max(mr, c);
+    mn = min(mn, c);
+  }
   const bool ok = (hi - lo + 1 <= WROWS) && (e1 - e0 <= EMAX);
   StageRec o;
   o.e0 = e0;
-  o.e1 = e1;
   o.lo = ok ? lo : (int)k0;
-  o.hi = ok ? hi : -1;
-  o.pad0 = o.pad1 = 0;
+  o.packed = ok ? ((unsigned)(e1 - e0) | ((unsigned)(hi - lo + 1) << 10) | ((unsigned)mr << 17) | ((mr == mn && k1 - k0 == PK ? 1u : 0u) << 27)) : 0u;
   rec[st] = o;
 }
 
-// Tile layout: wave w owns up to two rectangular blocks (rows i0..i0+ni-1 x columns j0..j0+nj-1 of the tile
-// grid).  Waves w and w + 4 share a SIMD; the layouts balance MFMA work per SIMD.
+// Tile layout: wave w owns one rectangular block (rows i0..i0+ni-1 x columns j0..j0+nj-1 of the tile grid).
+// Waves w and w + 4 share a SIMD; the layouts balance MFMA work per SIMD as far as the tile count allows
+// (r = 80: 25 tiles = 7 + 6 + 6 + 6; rotating the heavy SIMD with the workgroup index changed nothing measurable).
 struct Blk { int i0, ni, j0, nj; };
 template <int TR> struct Layout;
 #define NOBLK {0, 0, 0, 0}
-template <> struct Layout<1> { static constexpr Blk blk[8][2] = {{{0,1,0,1},NOBLK}, {NOBLK,NOBLK}, {NOBLK,NOBLK}, {NOBLK,NOBLK}, {NOBLK,NOBLK}, {NOBLK,NOBLK}, {NOBLK,NOBLK}, {NOBLK,NOBLK}}; };
-template <> struct Layout<2> { static constexpr Blk blk[8][2] = {{{0,1,0,1},NOBLK}, {{0,1,1,1},NOBLK}, {{1,1,0,1},NOBLK}, {{1,1,1,1},NOBLK}, {NOBLK,NOBLK}, {NOBLK,NOBLK}, {NOBLK,NOBLK}, {NOBLK,NOBLK}}; };
-template <> struct Layout<3> { static constexpr Blk blk[8][2] = {{{0,1,0,3},NOBLK}, {{1,1,0,2},NOBLK}, {{1,2,2,1},NOBLK}, {{2,1,0,2},NOBLK}, {NOBLK,NOBLK}, {NOBLK,NOBLK}, {NOBLK,NOBLK}, {NOBLK,NOBLK}}; };
-template <> struct Layout<4> { static constexpr Blk blk[8][2] = {{{0,1,0,2},NOBLK}, {{0,1,2,2},NOBLK}, {{1,1,0,2},NOBLK}, {{1,1,2,2},NOBLK}, {{2,1,0,2},NOBLK}, {{2,1,2,2},NOBLK}, {{3,1,0,2},NOBLK}, {{3,1,2,2},NOBLK}}; };
-template <> struct Layout<5> { static constexpr Blk blk[8][2] = {{{0,2,0,2},NOBLK}, {{0,2,2,2},NOBLK}, {{2,2,0,2},NOBLK}, {{2,2,2,2},NOBLK}, {{4,1,0,3},NOBLK}, {{0,2,4,1},NOBLK}, {{2,2,4,1},NOBLK}, {{4,1,3,2},NOBLK}}; };
-template <> struct Layout<6> { static constexpr Blk blk[8][2] = {{{0,2,0,3},NOBLK}, {{0,2,3,3},NOBLK}, {{2,2,0,3},NOBLK}, {{2,2,3,3},NOBLK}, {{4,1,0,3},NOBLK}, {{4,1,3,3},NOBLK}, {{5,1,0,3},NOBLK}, {{5,1,3,3},NOBLK}}; };
-template <> struct Layout<7> { static constexpr Blk blk[8][2] = {{{0,3,0,3},NOBLK}, {{0,3,3,3},NOBLK}, {{3,3,0,3},NOBLK}, {{3,3,3,3},NOBLK}, {{0,3,6,1},NOBLK}, {{3,3,6,1},NOBLK}, {{6,1,0,4},NOBLK}, {{6,1,4,3},NOBLK}}; };
-template <> struct Layout<8> { static constexpr Blk blk[8][2] = {{{0,2,0,4},NOBLK}, {{0,2,4,4},NOBLK}, {{2,2,0,4},NOBLK}, {{2,2,4,4},NOBLK}, {{4,2,0,4},NOBLK}, {{4,2,4,4},NOBLK}, {{6,2,0,4},NOBLK}, {{6,2,4,4},NOBLK}}; };
+template <> struct Layout<1> { static constexpr Blk blk[8] = {{0,1,0,1}, NOBLK, NOBLK, NOBLK, NOBLK, NOBLK, NOBLK, NOBLK}; };
+template <> struct Layout<2> { static constexpr Blk blk[8] = {{0,1,0,1}, {0,1,1,1}, {1,1,0,1}, {1,1,1,1}, NOBLK, NOBLK, NOBLK, NOBLK}; };
+template <> struct Layout<3> { static constexpr Blk blk[8] = {{0,1,0,3}, {1,1,0,2}, {1,2,2,1}, {2,1,0,2}, NOBLK, NOBLK, NOBLK, NOBLK}; };
+template <> struct Layout<4> { static constexpr Blk blk[8] = {{0,1,0,2}, {0,1,2,2}, {1,1,0,2}, {1,1,2,2}, {2,1,0,2}, {2,1,2,2}, {3,1,0,2}, {3,1,2,2}}; };
+template <> struct Layout<5> { static constexpr Blk blk[8] = {{0,2,0,2}, {0,2,2,2}, {2,2,0,2}, {2,2,2,2}, {4,1,0,3}, {0,2,4,1}, {2,2,4,1}, {4,1,3,2}}; };
+template <> struct Layout<6> { static constexpr Blk blk[8] = {{0,2,0,3}, {0,2,3,3}, {2,2,0,3}, {2,2,3,3}, {4,1,0,3}, {4,1,3,3}, {5,1,0,3}, {5,1,3,3}}; };
+template <> struct Layout<7> { static constexpr Blk blk[8] = {{0,3,0,3}, {0,3,3,3}, {3,3,0,3}, {3,3,3,3}, {0,3,6,1}, {3,3,6,1}, {6,1,0,4}, {6,1,4,3}}; };
+template <> struct Layout<8> { static constexpr Blk blk[8] = {{0,2,0,4}, {0,2,4,4}, {2,2,0,4}, {2,2,4,4}, {4,2,0,4}, {4,2,4,4}, {6,2,0,4}, {6,2,4,4}}; };
 #undef NOBLK
 
 template <int TR>
 constexpr bool layout_covers() {
   int seen[8][8] = {};
-  for (int w = 0; w < 8; ++w)
-    for (int q = 0; q < 2; ++q) {
-      const Blk b = Layout<TR>::blk[w][q];
-      for (int i = b.i0; i < b.i0 + b.ni; ++i)
-        for (int j = b.j0; j < b.j0 + b.nj; ++j) ++seen[i][j];
-    }
+  for (int w = 0; w < 8; ++w) {
+    const Blk b = Layout<TR>::blk[w];
+    for (int i = b.i0; i < b.i0 + b.ni; ++i)
+      for (int j = b.j0; j < b.j0 + b.nj; ++j) ++seen[i][j];
+  }
   for (int i = 0; i < TR; ++i)
     for (int j = 0; j < TR; ++j)
       if (seen[i][j] != 1) return false;
@@ -121,24 +147,6 @@ constexpr bool layout_covers() {
 static_assert(layout_covers<1>() && layout_covers<2>() && layout_covers<3>() && layout_covers<4>() &&
                   layout_covers<5>() && layout_covers<6>() && layout_covers<7>() && layout_covers<8>(),
               "every output tile belongs to exactly one wave");
-
-// One k-step (4 rows of the stage) of an NI x NJ block: NI + NJ LDS reads at immediate offsets, NI*NJ MFMAs.
-template <int STRIDE, int NI, int NJ>
-__device__ __forceinline__ void block_step(const double* lA, const double* lB, int k4, int i0, int j0,
-                                           d4 (&acc)[NI * NJ > 0 ? NI * NJ : 1]) {
-  if constexpr (NI * NJ > 0) {
-    double a[NI], bq[NJ];
-#pragma unroll
-    for (int i = 0; i < NI; ++i) a[i] = lA[k4 * 4 * STRIDE + 16 * (i0 + i)];
-#pragma unroll
-    for (int j = 0; j < NJ; ++j) bq[j] = lB[k4 * 4 * STRIDE + 16 * (j0 + j)];
-#pragma unroll
-    for (int i = 0; i < NI; ++i)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        acc[i * NJ + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bq[j], acc[i * NJ + j], 0, 0, 0);
-  }
-}
 
 template <int NI, int NJ>
 __device__ __forceinline__ void block_store(double* out, int r, int i0, int j0, int l4, int l15,
@@ -156,140 +164,186 @@ __device__ __forceinline__ void block_store(double* out, int r, int i0, int j0, 
   }
 }
 
-// The whole stage loop for wave W (compile-time tile blocks).  Software-pipelined: while stage s is computed
-// out of LDS, the entries, the per-row entry ranges and the V-row window of stage s+1 are in flight into
-// registers (their addresses come from the stage record fetched during stage s-1, so no load waits on another
-// load); they are written to LDS after the MFMAs of stage s.
+// The whole stage loop for the wave that owns block W of the layout (compile-time tiles).  Software-pipelined:
+// while stage s is computed out of LDS, the entries, the per-row entry ranges and the V-row window of stage
+// s+1 are in flight into registers (their addresses come from the stage record fetched during stage s-1, so
+// no load waits on another load); they are written to LDS after the MFMAs of stage s.
 template <int TR, int W>
 __device__ __forceinline__ void project_wave(const ProjParams& p, double* sm) {
   constexpr int STRIDE = stride_of(TR);
-  constexpr int rp = TR * 16;
-  constexpr int PAIRS = rp / 2;                               // d2 pairs per window row
-  constexpr int NW = (WROWS * PAIRS + PT - 1) / PT;           // window pairs per thread
-  constexpr Blk b0 = Layout<TR>::blk[W][0], b1 = Layout<TR>::blk[W][1];
-  constexpr int N0 = b0.ni * b0.nj, N1 = b1.ni * b1.nj;
+  constexpr int PAIRS = 8 * TR;                               // d2 pairs per window row
+  constexpr int RPP = PT / PAIRS;                             // window rows per pass of the workgroup
+  constexpr int NWP = (WROWS + RPP - 1) / RPP;                // passes = d2 loads per thread and stage
+  constexpr Blk b0 = Layout<TR>::blk[W];
+  constexpr int NI = b0.ni, NJ = b0.nj, NT = NI * NJ;
+  constexpr int U = TR <= 2 ? 6 : (TR <= 4 ? 3 : 2);          // entries per gather chunk (2 U TR transient VGPRs)
+  static_assert(U <= EPAD, "a chunk may overrun the staged entries by U - 1");
   double* sW = sm;                                            // [WROWS][STRIDE]  window of V rows
   double* sB = sm + WROWS * STRIDE;                           // [PK][STRIDE]     rows of A_b V
-  Entry* sEnt = reinterpret_cast<Entry*>(sB + PK * STRIDE);   // [EMAX]
+  Entry* sEnt = reinterpret_cast<Entry*>(sB + PK * STRIDE);   // [EMAX + EPAD]
   const int tid = threadIdx.x, lane = tid & 63;
   const int l15 = lane & 15, l4 = lane >> 4;
   const int b = blockIdx.x % p.B, s = blockIdx.x / p.B;
   const int r = p.r;
-  const long kbeg = (long)s * p.k_per_split;
-  const long kend = (kbeg + p.k_per_split < p.N) ? kbeg + p.k_per_split : p.N;
+  const int kbeg = s * p.k_per_split;                         // multiple of PK
+  const int kend = (kbeg + p.k_per_split < p.N) ? kbeg + p.k_per_split : p.N;
   const double* dat = p.data + (long)b * p.d_bs;
-  const bool vec2 = ((p.ldv & 1) == 0) && ((reinterpret_cast<size_t>(p.V) & 15) == 0);
+  const bool vec2 = ((p.ldv & 1) == 0) && ((reinterpret_cast<size_t>(p.V) & 15) == 0) && ((r & 1) == 0) && !PF_ABLATE(8);
 
-  d4 acc0[N0 > 0 ? N0 : 1], acc1[N1 > 0 ? N1 : 1];
+  d4 acc[NT > 0 ? NT : 1];
 #pragma unroll
-  for (int q = 0; q < (N0 > 0 ? N0 : 1); ++q) acc0[q] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-  for (int q = 0; q < (N1 > 0 ? N1 : 1); ++q) acc1[q] = d4{0.0, 0.0, 0.0, 0.0};
+  for (int q = 0; q < (NT > 0 ? NT : 1); ++q) acc[q] = d4{0.0, 0.0, 0.0, 0.0};
 
-  // per-thread constants of the window copy: pair q of the thread sits at row w_row[q], columns 2 cp, 2 cp + 1
-  unsigned w_goff[NW];
-  int w_loff[NW], w_row[NW];
-  bool w_c0[NW], w_c1[NW];
-#pragma unroll
-  for (int q = 0; q < NW; ++q) {
-    const int pidx = tid + PT * q;
-    const int row = pidx / PAIRS, cp = pidx % PAIRS;
-    w_row[q] = (row < WROWS) ? row : (1 << 20);   // never < nrow
-    w_goff[q] = (row * (int)p.ldv + 2 * cp) * 8;  // bytes
-    w_loff[q] = row * STRIDE + 2 * cp;
-    w_c0[q] = 2 * cp < r;
-    w_c1[q] = 2 * cp + 1 < r;
-  }
+  // window copy: pass q of the workgroup covers rows RPP q .. RPP q + RPP - 1 of the window; this thread takes
+  // columns 2 cp, 2 cp + 1 of row wrow + RPP q.  Its global and LDS offsets differ between passes by
+  // wave-uniform / compile-time amounts, so two registers describe all NWP loads.
+  const int wrow = (tid < RPP * PAIRS) ? tid / PAIRS : (1 << 20);
+  const int cp = tid % PAIRS;
+  const unsigned w_goff = (unsigned)(((tid / PAIRS) * (int)p.ldv + 2 * cp) * 8);  // bytes
+  double* w_lds = sW + (tid / PAIRS) * STRIDE + 2 * cp;
+  const unsigned pass32 = (unsigned)(RPP * (int)p.ldv * 8);   // bytes between passes of the window copy
   const int kk = tid >> 4, jg = tid & 15;  // gather mapping: row kk of the stage, columns jg + 16 c
 
   // registers of the stage in flight
-  d2 wreg[NW];
+  d2 wreg[NWP];
   double vreg = 0.0;
   int creg = 0, nb_lo = 0, nb_hi = 0;
-  StageRec rn{};
 
-  // every global address below is (wave-uniform base) + (32-bit per-thread offset): the loads use the
-  // scalar-base addressing mode and need no 64-bit VALU arithmetic
+  // every global address below is (wave-uniform base) + (32-bit per-thread offset)
   const unsigned ent_off = (unsigned)tid * (unsigned)p.d_es * 8u, idx_off = (unsigned)tid * 8u, row_off = (unsigned)kk * 8u;
   auto ld = [](const void* base, unsigned off) { return *reinterpret_cast<const double*>(static_cast<const char*>(base) + off); };
-  auto ldi = [](const void* base, unsigned off) { return (int)*reinterpret_cast<const long*>(static_cast<const char*>(base) + off); };
-  auto fetch = [&](long k0, const StageRec& rc) {  // issue the loads of stage k0 (no LDS access, no dependent load)
-    rn = rc;
-    const int rows_left = (int)((kend - k0 < PK) ? kend - k0 : PK);
-    const int nrow = (rc.hi >= 0) ? (rc.hi - rc.lo + 1) : rows_left;
-    const double* vbase = p.V + (long)rc.lo * p.ldv;  // wave-uniform
+  auto ldi = [](const void* base, unsigned off) { return *reinterpret_cast<const int*>(static_cast<const char*>(base) + off); };
+  // Full windowed stages (all but the ends of the matrix) load through buffer descriptors: the address is
+  // descriptor base + per-thread 32-bit offset (a constant of the thread) + a scalar offset, and lanes past the
+  // stage's entries are dropped by the range check - not one vector instruction per load.  Window rows past the
+  // stage's last column and the idle threads' rows are read too (they exist: lo + NWP RPP < N) and never used.
+  const __amdgpu_buffer_rsrc_t rsV = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p.V), 0, 0xffffffffu, 0x00020000);
+  auto fetch = [&](int k0, const StageRec& rc) {  // issue the loads of stage k0 (no LDS access, no dependent load)
+    const int rows_left = (kend - k0 < PK) ? kend - k0 : PK;
+    const int nr = rec_nrow(rc.packed);
+    if (vec2 && nr > 0 && rows_left == PK && rc.lo + NWP * RPP < p.N) {
+      const unsigned so = (unsigned)rc.lo * (unsigned)p.ldv * 8u;
 #pragma unroll
-    for (int q = 0; q < NW; ++q) {
+      for (int q = 0; q < NWP; ++q)
+        wreg[q] = __builtin_bit_cast(d2, __builtin_amdgcn_raw_buffer_load_b128(rsV, w_goff, so + q * pass32, 0));
+      const unsigned ne = (unsigned)rec_ne(rc.packed);
+      const __amdgpu_buffer_rsrc_t rsD = __builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(dat + rc.e0 * p.d_es), 0, ne * (unsigned)p.d_es * 8u, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(const_cast<long*>(p.indices + rc.e0), 0, ne * 8u, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<long*>(p.indptr + k0), 0, (PK + 1) * 8u, 0x00020000);
+      vreg = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsD, ent_off, 0, 0));
+      creg = (int)__builtin_amdgcn_raw_buffer_load_b32(rsI, idx_off, 0, 0) - rc.lo;   // low words: all of it is < 2^31
+      const u4 t = __builtin_amdgcn_raw_buffer_load_b128(rsP, row_off, 0, 0);
+      nb_lo = (int)t.x;
+      nb_hi = (int)t.z;
+      return;
+    }
+    const int nrow = nr > 0 ? nr : rows_left;
+    const char* vbase = reinterpret_cast<const char*>(p.V + (long)rc.lo * p.ldv);  // wave-uniform
+#pragma unroll
+    for (int q = 0; q < NWP; ++q) {
       d2 v{0.0, 0.0};
-      if (w_row[q] < nrow) {
-        const char* src = reinterpret_cast<const char*>(vbase) + w_goff[q];
-        if (vec2 && w_c1[q]) {
-          v = *reinterpret_cast<const d2*>(src);
-        } else {
-          if (w_c0[q]) v.x = *reinterpret_cast<const double*>(src);
-          if (w_c1[q]) v.y = *reinterpret_cast<const double*>(src + 8);
-        }
+      if (wrow < nrow - RPP * q) {
+        const char* src = vbase + (w_goff + q * pass32);
+        if (2 * cp < r) v.x = *reinterpret_cast<const double*>(src);
+        if (2 * cp + 1 < r) v.y = *reinterpret_cast<const double*>(src + 8);
       }
       wreg[q] = v;
     }
-    if (rc.hi >= 0) {
-      const bool v = tid < (int)(rc.e1 - rc.e0);
+    if (nr > 0) {
+      const bool v = tid < rec_ne(rc.packed);
       vreg = v ? ld(dat + rc.e0 * p.d_es, ent_off) : 0.0;
       creg = v ? ldi(p.indices + rc.e0, idx_off) - rc.lo : 0;
-      const bool rv = kk < rows_left;  // entry range of this thread's row, low words (a stage holds < 2^31 entries)
+      const bool rv = kk < rows_left;
       nb_lo = rv ? ldi(p.indptr + k0, row_off) : 0;
       nb_hi = rv ? ldi(p.indptr + k0 + 1, row_off) : 0;
     }
   };
-  int c_lo = 0, c_hi = -1, row_base = 0, row_cnt = 0;
-  auto commit = [&]() {  // registers -> LDS
+  int c_lo = 0, row_cnt = 0;
+  unsigned c_pk = 0;   // packed fields of the committed stage
+  const Entry* ep = sEnt;
+  auto commit = [&](const StageRec& rc) {  // registers -> LDS; rc = the record fetch() was given
+    if (RPP * PAIRS == PT || wrow < RPP) {   // threads past the last whole row of a pass hold nothing
 #pragma unroll
-    for (int q = 0; q < NW; ++q)
-      if (w_row[q] < WROWS) *reinterpret_cast<d2*>(sW + w_loff[q]) = wreg[q];
+      for (int q = 0; q < NWP; ++q)
+        if (RPP * (q + 1) <= WROWS || wrow < WROWS - RPP * q) *reinterpret_cast<d2*>(w_lds + q * RPP * STRIDE) = wreg[q];
+    }
     Entry en;
     en.val = vreg;
     en.rowoff = creg * STRIDE * (int)sizeof(double);
     en.pad = 0;
     sEnt[tid] = en;
-    c_lo = rn.lo;
-    c_hi = rn.hi;
-    row_base = nb_lo - (int)rn.e0;
+    c_lo = rc.lo;
+    c_pk = rc.packed;
+    ep = sEnt + (nb_lo - (int)rc.e0);
     row_cnt = nb_hi - nb_lo;
   };
 
-  const long st0 = kbeg / PK;
+  const int st0 = kbeg / PK, st1 = (kend + PK - 1) / PK;
   StageRec r1{}, r2{};
-  if (kbeg < kend) {
+  if (st0 < st1) {
     r1 = p.rec[st0];
-    if (kbeg + PK < kend) r2 = p.rec[st0 + 1];
+    if (st0 + 1 < st1) r2 = p.rec[st0 + 1];
     fetch(kbeg, r1);
-    commit();
+    commit(r1);
   }
   __syncthreads();
 
   const char* sWc = reinterpret_cast<const char*>(sW) + jg * sizeof(double);
   double* brow = sB + kk * STRIDE + jg;
-  const double* lB = sB + l4 * STRIDE + l15;
-  long st = st0;
-  for (long k0 = kbeg; k0 < kend; k0 += PK, ++st) {
-    const bool more = (k0 + PK < kend);
+  const double* lB = sB + l4 * STRIDE + l15 + 16 * b0.j0;
+  const double* lA0 = sW + l4 * STRIDE + l15 + 16 * b0.i0;
+  __builtin_amdgcn_s_setprio(3);
+  for (int st = st0; st < st1; ++st) {
+    const int k0 = st * PK;
+    const bool more = st + 1 < st1;
     if (more) {
-      r1 = r2;                                      // loaded one stage ago
-      if (k0 + 2 * PK < kend) r2 = p.rec[st + 2];   // for the next iteration
-      fetch(k0 + PK, r1);
+      r1 = r2;                                    // loaded one stage ago
+      if (st + 2 < st1) r2 = p.rec[st + 2];       // for the next iteration
+      if (!PF_ABLATE(64)) fetch(k0 + PK, r1);
     }
-    // B operand: rows of A_b V
+    // B operand: rows of A_b V.  The entries of a row are taken U at a time: U entry reads, then their U TR
+    // window reads, then the FMAs - two LDS round trips per chunk (one read after another costs four per entry).
     {
       double o[TR];
 #pragma unroll
       for (int c = 0; c < TR; ++c) o[c] = 0.0;
-      if (c_hi >= 0) {
-        for (int q = 0; q < row_cnt; ++q) {
-          const Entry en = sEnt[row_base + q];
-          const double* vr = reinterpret_cast<const double*>(sWc + en.rowoff);
+      if (PF_ABLATE(16)) {
+      } else if (rec_nrow(c_pk) > 0) {
+        auto chunk = [&](auto uc, auto masked, int q0) {
+          constexpr int UC = decltype(uc)::value;
+          Entry en[UC];
 #pragma unroll
-          for (int c = 0; c < TR; ++c) o[c] = fma(en.val, vr[16 * c], o[c]);
-        }
+          for (int u = 0; u < UC; ++u) en[u] = ep[q0 + u];
+          if constexpr (decltype(masked)::value) {
+#pragma unroll
+            for (int u = 0; u < UC; ++u) en[u].val = (q0 + u < row_cnt) ? en[u].val : 0.0;
+          }
+          double x[UC][TR];
+#pragma unroll
+          for (int u = 0; u < UC; ++u) {
+            const double* vr = reinterpret_cast<const double*>(sWc + en[u].rowoff);
+#pragma unroll
+            for (int c = 0; c < TR; ++c) x[u][c] = vr[16 * c];
+          }
+#pragma unroll
+          for (int u = 0; u < UC; ++u)
+#pragma unroll
+            for (int c = 0; c < TR; ++c) o[c] = fma(en[u].val, x[u][c], o[c]);
+        };
+        auto row_sum = [&](auto masked) {
+          const int c_mr = rec_mr(c_pk);
+          int q0 = 0;
+          for (; q0 + U <= c_mr; q0 += U) chunk(std::integral_constant<int, U>{}, masked, q0);
+          const int rest = c_mr - q0;   // wave-uniform
+          if constexpr (U > 1) { if (rest == 1) chunk(std::integral_constant<int, 1>{}, masked, q0); }
+          if constexpr (U > 2) { if (rest == 2) chunk(std::integral_constant<int, 2>{}, masked, q0); }
+          if constexpr (U > 3) { if (rest == 3) chunk(std::integral_constant<int, 3>{}, masked, q0); }
+          if constexpr (U > 4) { if (rest == 4) chunk(std::integral_constant<int, 4>{}, masked, q0); }
+          if constexpr (U > 5) { if (rest == 5) chunk(std::integral_constant<int, 5>{}, masked, q0); }
+        };
+        // rows of equal length (the interior of a structured operator) need no per-thread predicate
+        if (rec_uni(c_pk)) row_sum(std::false_type{});
+        else row_sum(std::true_type{});
       } else if (k0 + kk < kend) {
         const long k = k0 + kk;
         const long e0 = p.indptr[k], e1 = p.indptr[k + 1];
@@ -305,29 +359,47 @@ __device__ __forceinline__ void project_wave(const ProjParams& p, double* sm) {
       for (int c = 0; c < TR; ++c) brow[16 * c] = o[c];
     }
     __syncthreads();
-    if constexpr (N0 > 0) {
-      const double* lA = sW + ((int)(k0 - c_lo) + l4) * STRIDE + l15;  // LDS row of DoF k0 (+ this lane's k)
+    __builtin_amdgcn_s_setprio(0);
+    if constexpr (NT > 0) if (!PF_ABLATE(32)) {
+      // operands of k-step k4 + 1 are read before the MFMAs of k-step k4 are issued
+      const double* lA = lA0 + (k0 - c_lo) * STRIDE;  // LDS row of DoF k0 (+ this lane's k)
+      double a[2][NI], bq[2][NJ];
+#pragma unroll
+      for (int i = 0; i < NI; ++i) a[0][i] = lA[16 * i];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) bq[0][j] = lB[16 * j];
 #pragma unroll
       for (int k4 = 0; k4 < PK / 4; ++k4) {
-        block_step<STRIDE, b0.ni, b0.nj>(lA, lB, k4, b0.i0, b0.j0, acc0);
-        block_step<STRIDE, b1.ni, b1.nj>(lA, lB, k4, b1.i0, b1.j0, acc1);
+        const int cur = k4 & 1, nxt = cur ^ 1;
+        if (k4 + 1 < PK / 4) {
+#pragma unroll
+          for (int i = 0; i < NI; ++i) a[nxt][i] = lA[(k4 + 1) * 4 * STRIDE + 16 * i];
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) bq[nxt][j] = lB[(k4 + 1) * 4 * STRIDE + 16 * j];
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the reads ahead of the MFMAs they are to hide behind
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i * NJ + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][i], bq[cur][j], acc[i * NJ + j], 0, 0, 0);
       }
     }
+    __builtin_amdgcn_s_setprio(3);   // gather, fetch and commit phases win the issue slot over the other workgroup's MFMAs
     __syncthreads();
-    if (more) commit();
+    if (more) commit(r1);
     __syncthreads();
   }
   double* out = p.slab + ((long)b * p.S + s) * ((long)r * r);
-  block_store<b0.ni, b0.nj>(out, r, b0.i0, b0.j0, l4, l15, acc0);
-  block_store<b1.ni, b1.nj>(out, r, b1.i0, b1.j0, l4, l15, acc1);
+  block_store<NI, NJ>(out, r, b0.i0, b0.j0, l4, l15, acc);
 }
 
 template <int TR>
 __global__ __launch_bounds__(PT, TR <= 5 ? 4 : 2) void project_fused_kernel(const ProjParams p) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   // a short last stage lets the A operand reach rows past the window (they only meet zero rows of B, but must be
-  // finite): no LDS word is ever read uninitialised
-  constexpr int words = (WROWS + PK) * stride_of(TR);
+  // finite): no LDS word is ever read uninitialised; the entries behind the staged ones stay zero
+  constexpr int words = (WROWS + PK) * stride_of(TR) + 2 * (EMAX + EPAD);
   for (int i = threadIdx.x; i < words; i += PT) sm[i] = 0.0;
   __syncthreads();
   switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {  // one code path per wave: its tiles are constants
@@ -368,7 +440,7 @@ int rt_project_stage_table(rt_ctx* ctx, const int64_t* indptr, const int64_t* in
 
 template <int TR>
 static constexpr size_t fused_lds() {
-  return sizeof(double) * (size_t)(WROWS + PK) * stride_of(TR) + sizeof(Entry) * EMAX;
+  return sizeof(double) * (size_t)(WROWS + PK) * stride_of(TR) + sizeof(Entry) * (EMAX + EPAD);
 }
 
 // workgroups of project_fused_kernel<TR> that fit one CU (LDS and registers), asked of the runtime once per TR
@@ -400,7 +472,7 @@ static int fused_blocks_per_cu(rt_ctx* ctx, int tr, int* out) {
 
 template <int TR>
 static int launch_fused(rt_ctx* ctx, const ProjParams& p, unsigned grid) {
-  hipLaunchKernelGGL((project_fused_kernel<TR>), dim3(grid), dim3(PT), fused_lds<TR>(), ctx->stream, p);
+  hipLaunchKernelGGL((project_fused_kernel<TR>), dim3(grid), dim3(PT), fused_lds<TR>() , ctx->stream, p);
   RT_HIP_CHECK(ctx, hipGetLastError());
   return RT_OK;
 }
@@ -411,13 +483,19 @@ int rt_project_fused(rt_ctx* ctx, const int64_t* indptr, const int64_t* indices,
                      int64_t d_bs, int64_t B, int64_t N, const double* V, int64_t ldv, int64_t r, double* AN,
                      const void* stage_table) {
   if (r > RMAX) return RT_ERR_UNSUPPORTED;
-  if (((int64_t)WROWS * ldv + RMAX) * 8 >= (1LL << 31) || d_es * 8 * EMAX >= (1LL << 31))
-    return RT_ERR_UNSUPPORTED;  // 32-bit per-thread byte offsets
+  if (((int64_t)WROWS * ldv + RMAX) * 8 >= (1LL << 31) || d_es * 8 * EMAX >= (1LL << 31) || N >= (1LL << 31) - 2 * PK ||
+      N * ldv * 8 >= (1LL << 32))
+    return RT_ERR_UNSUPPORTED;  // 32-bit per-thread byte offsets, 32-bit row counters
+#ifdef ROMTIME_PF_ABLATE
+  static const int pf_flags = [] { const char* e = getenv("ROMTIME_PF_FLAGS"); return e ? atoi(e) : 0; }();
+#else
+  const int pf_flags = 0;
+#endif
   ProjParams p;
   p.indptr = reinterpret_cast<const long*>(indptr);
   p.indices = reinterpret_cast<const long*>(indices);
   p.data = data; p.d_es = d_es; p.d_bs = d_bs;
-  p.V = V; p.ldv = ldv; p.N = N; p.r = (int)r; p.B = (int)B;
+  p.V = V; p.ldv = ldv; p.N = (int)N; p.r = (int)r; p.B = (int)B; p.flags = pf_flags;
   const int tr = (int)((r + 15) / 16), rp = tr * 16;
   // DoF ranges per value vector: about two rounds of resident workgroups (so that gather and MFMA phases of
   // different workgroups overlap), chosen so that the LAST round is full too - 120 vectors x 9 ranges on 512
@@ -441,7 +519,7 @@ int rt_project_fused(rt_ctx* ctx, const int64_t* indptr, const int64_t* indices,
     const double fill = (double)g / (double)(rounds * resident);
     if (fill >= best) { best = fill; S = s_eff; kps = per; }   // ties: more, smaller ranges
   }
-  p.k_per_split = kps;
+  p.k_per_split = (int)kps;
   p.S = (int)S;
   void* slab = nullptr;
   const size_t slab_bytes = (sizeof(double) * (size_t)B * S * r * r + 255) / 256 * 256;
