@@ -74,6 +74,9 @@ struct Entry {  // staged entry: value and byte offset of its V row inside the L
 };
 constexpr int EPAD = 8;       // zero entries behind the staged ones (a gather chunk may read past the last entry)
 
+// The table starts with a 16-byte header: word 0 != 0 when some stage of the pattern cannot be windowed.
+constexpr size_t TABLE_HEADER = 16;
+
 struct ProjParams {
   const long* indptr;
   const long* indices;
@@ -86,10 +89,11 @@ struct ProjParams {
   int r, B, S;
   int flags;
   const StageRec* rec;  // [stages]
+  const int* any_unwindowed;
 };
 
 __global__ void project_stages_kernel(const long* __restrict__ indptr, const long* __restrict__ indices, long N,
-                                      StageRec* __restrict__ rec) {
+                                      StageRec* __restrict__ rec, int* __restrict__ any_unwindowed) {
   const long st = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long k0 = st * PK;
   if (k0 >= N) return;
@@ -113,6 +117,7 @@ __global__ void project_stages_kernel(const long* __restrict__ indptr, const lon
   o.lo = ok ? lo : (int)k0;
   o.packed = ok ? ((unsigned)(e1 - e0) | ((unsigned)(hi - lo + 1) << 10) | ((unsigned)mr << 17) | ((mr == mn && k1 - k0 == PK ? 1u : 0u) << 27)) : 0u;
   rec[st] = o;
+  if (!ok) atomicOr(any_unwindowed, 1);
 }
 
 // Tile layout: wave w owns one rectangular block (rows i0..i0+ni-1 x columns j0..j0+nj-1 of the tile grid).
@@ -168,7 +173,7 @@ __device__ __forceinline__ void block_store(double* out, int r, int i0, int j0, 
 // while stage s is computed out of LDS, the entries, the per-row entry ranges and the V-row window of stage
 // s+1 are in flight into registers (their addresses come from the stage record fetched during stage s-1, so
 // no load waits on another load); they are written to LDS after the MFMAs of stage s.
-template <int TR, int W>
+template <int TR, int W, bool MIXED>
 __device__ __forceinline__ void project_wave(const ProjParams& p, double* sm) {
   constexpr int STRIDE = stride_of(TR);
   constexpr int PAIRS = 8 * TR;                               // d2 pairs per window row
@@ -231,10 +236,11 @@ __device__ __forceinline__ void project_wave(const ProjParams& p, double* sm) {
       const __amdgpu_buffer_rsrc_t rsI = __builtin_amdgcn_make_buffer_rsrc(const_cast<long*>(p.indices + rc.e0), 0, ne * 8u, 0x00020000);
       const __amdgpu_buffer_rsrc_t rsP = __builtin_amdgcn_make_buffer_rsrc(const_cast<long*>(p.indptr + k0), 0, (PK + 1) * 8u, 0x00020000);
       vreg = __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsD, ent_off, 0, 0));
-      creg = (int)__builtin_amdgcn_raw_buffer_load_b32(rsI, idx_off, 0, 0) - rc.lo;   // low words: all of it is < 2^31
-      const u4 t = __builtin_amdgcn_raw_buffer_load_b128(rsP, row_off, 0, 0);
-      nb_lo = (int)t.x;
-      nb_hi = (int)t.z;
+      creg = (int)__builtin_amdgcn_raw_buffer_load_b32(rsI, idx_off, 0, 0);   // low word (< 2^31); `- lo` waits for commit()
+      // two dword loads: a wider one leaves dead destination registers, which the allocator hands out again and
+      // the hazard logic then protects with a full vmcnt(0) in the middle of the gather
+      nb_lo = (int)__builtin_amdgcn_raw_buffer_load_b32(rsP, row_off, 0, 0);
+      nb_hi = (int)__builtin_amdgcn_raw_buffer_load_b32(rsP, row_off + 8u, 0, 0);
       return;
     }
     const int nrow = nr > 0 ? nr : rows_left;
@@ -252,7 +258,7 @@ __device__ __forceinline__ void project_wave(const ProjParams& p, double* sm) {
     if (nr > 0) {
       const bool v = tid < rec_ne(rc.packed);
       vreg = v ? ld(dat + rc.e0 * p.d_es, ent_off) : 0.0;
-      creg = v ? ldi(p.indices + rc.e0, idx_off) - rc.lo : 0;
+      creg = v ? ldi(p.indices + rc.e0, idx_off) : rc.lo;
       const bool rv = kk < rows_left;
       nb_lo = rv ? ldi(p.indptr + k0, row_off) : 0;
       nb_hi = rv ? ldi(p.indptr + k0 + 1, row_off) : 0;
@@ -269,7 +275,7 @@ __device__ __forceinline__ void project_wave(const ProjParams& p, double* sm) {
     }
     Entry en;
     en.val = vreg;
-    en.rowoff = creg * STRIDE * (int)sizeof(double);
+    en.rowoff = (creg - rc.lo) * STRIDE * (int)sizeof(double);   // no arithmetic on loaded values before this point
     en.pad = 0;
     sEnt[tid] = en;
     c_lo = rc.lo;
@@ -344,7 +350,7 @@ __device__ __forceinline__ void project_wave(const ProjParams& p, double* sm) {
         // rows of equal length (the interior of a structured operator) need no per-thread predicate
         if (rec_uni(c_pk)) row_sum(std::false_type{});
         else row_sum(std::true_type{});
-      } else if (k0 + kk < kend) {
+      } else if (MIXED && k0 + kk < kend) {   // a stage that could not be windowed: straight out of global memory
         const long k = k0 + kk;
         const long e0 = p.indptr[k], e1 = p.indptr[k + 1];
         for (long e = e0; e < e1; ++e) {
@@ -394,8 +400,13 @@ __device__ __forceinline__ void project_wave(const ProjParams& p, double* sm) {
   block_store<NI, NJ>(out, r, b0.i0, b0.j0, l4, l15, acc);
 }
 
-template <int TR>
+// MIXED = false is the kernel for patterns whose stages are all windowed (banded operators): without the
+// global-memory gather in the same code the hazard logic keeps the loads of stage s+1 in flight across the whole of
+// stage s (with it, a vmcnt(0) lands in front of the MFMAs).  Both variants are launched; the one the table's
+// header does not ask for returns at once, so the host never has to read the header back.
+template <int TR, bool MIXED>
 __global__ __launch_bounds__(PT, TR <= 5 ? 4 : 2) void project_fused_kernel(const ProjParams p) {
+  if ((*p.any_unwindowed != 0) != MIXED) return;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   // a short last stage lets the A operand reach rows past the window (they only meet zero rows of B, but must be
   // finite): no LDS word is ever read uninitialised; the entries behind the staged ones stay zero
@@ -403,14 +414,14 @@ __global__ __launch_bounds__(PT, TR <= 5 ? 4 : 2) void project_fused_kernel(cons
   for (int i = threadIdx.x; i < words; i += PT) sm[i] = 0.0;
   __syncthreads();
   switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {  // one code path per wave: its tiles are constants
-    case 0: project_wave<TR, 0>(p, sm); break;
-    case 1: project_wave<TR, 1>(p, sm); break;
-    case 2: project_wave<TR, 2>(p, sm); break;
-    case 3: project_wave<TR, 3>(p, sm); break;
-    case 4: project_wave<TR, 4>(p, sm); break;
-    case 5: project_wave<TR, 5>(p, sm); break;
-    case 6: project_wave<TR, 6>(p, sm); break;
-    default: project_wave<TR, 7>(p, sm); break;
+    case 0: project_wave<TR, 0, MIXED>(p, sm); break;
+    case 1: project_wave<TR, 1, MIXED>(p, sm); break;
+    case 2: project_wave<TR, 2, MIXED>(p, sm); break;
+    case 3: project_wave<TR, 3, MIXED>(p, sm); break;
+    case 4: project_wave<TR, 4, MIXED>(p, sm); break;
+    case 5: project_wave<TR, 5, MIXED>(p, sm); break;
+    case 6: project_wave<TR, 6, MIXED>(p, sm); break;
+    default: project_wave<TR, 7, MIXED>(p, sm); break;
   }
 }
 
@@ -427,13 +438,14 @@ __global__ void project_reduce_kernel(const double* __restrict__ slab, int S, lo
 
 }  // namespace
 
-size_t rt_project_stage_table_bytes(int64_t N) { return sizeof(StageRec) * (size_t)((N + PK - 1) / PK); }
+size_t rt_project_stage_table_bytes(int64_t N) { return TABLE_HEADER + sizeof(StageRec) * (size_t)((N + PK - 1) / PK); }
 
 int rt_project_stage_table(rt_ctx* ctx, const int64_t* indptr, const int64_t* indices, int64_t N, void* table) {
   const long stages = (N + PK - 1) / PK;
+  RT_HIP_CHECK(ctx, hipMemsetAsync(table, 0, TABLE_HEADER, ctx->stream));
   hipLaunchKernelGGL(project_stages_kernel, dim3((unsigned)((stages + 255) / 256)), dim3(256), 0, ctx->stream,
                      reinterpret_cast<const long*>(indptr), reinterpret_cast<const long*>(indices), (long)N,
-                     static_cast<StageRec*>(table));
+                     reinterpret_cast<StageRec*>(static_cast<char*>(table) + TABLE_HEADER), static_cast<int*>(table));
   RT_HIP_CHECK(ctx, hipGetLastError());
   return RT_OK;
 }
@@ -447,10 +459,11 @@ static constexpr size_t fused_lds() {
 template <int TR>
 static int fused_blocks_per_cu(rt_ctx* ctx, int* out) {
   static int cached = 0;  // occupancy is a property of the kernel on gfx950, the same on every device of the node
-  RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&project_fused_kernel<TR>), 104 * 1024));
+  RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&project_fused_kernel<TR, false>), 104 * 1024));
+  RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&project_fused_kernel<TR, true>), 104 * 1024));
   if (cached == 0) {
     int nb = 0;
-    RT_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, project_fused_kernel<TR>, PT, fused_lds<TR>()));
+    RT_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, project_fused_kernel<TR, false>, PT, fused_lds<TR>()));
     cached = nb > 0 ? nb : 1;
   }
   *out = cached;
@@ -472,7 +485,8 @@ static int fused_blocks_per_cu(rt_ctx* ctx, int tr, int* out) {
 
 template <int TR>
 static int launch_fused(rt_ctx* ctx, const ProjParams& p, unsigned grid) {
-  hipLaunchKernelGGL((project_fused_kernel<TR>), dim3(grid), dim3(PT), fused_lds<TR>() , ctx->stream, p);
+  hipLaunchKernelGGL((project_fused_kernel<TR, false>), dim3(grid), dim3(PT), fused_lds<TR>(), ctx->stream, p);
+  hipLaunchKernelGGL((project_fused_kernel<TR, true>), dim3(grid), dim3(PT), fused_lds<TR>(), ctx->stream, p);
   RT_HIP_CHECK(ctx, hipGetLastError());
   return RT_OK;
 }
@@ -527,12 +541,14 @@ int rt_project_fused(rt_ctx* ctx, const int64_t* indptr, const int64_t* indices,
   if (rc != RT_OK) return rc;
   p.slab = static_cast<double*>(slab);
   if (stage_table) {
-    p.rec = static_cast<const StageRec*>(stage_table);
+    p.any_unwindowed = static_cast<const int*>(stage_table);
+    p.rec = reinterpret_cast<const StageRec*>(static_cast<const char*>(stage_table) + TABLE_HEADER);
   } else {
     void* table = static_cast<char*>(slab) + slab_bytes;
     rc = rt_project_stage_table(ctx, indptr, indices, N, table);
     if (rc != RT_OK) return rc;
-    p.rec = static_cast<const StageRec*>(table);
+    p.any_unwindowed = static_cast<const int*>(table);
+    p.rec = reinterpret_cast<const StageRec*>(static_cast<const char*>(table) + TABLE_HEADER);
   }
   if (ctx->profile) {
     if (!ctx->ev0) {
