@@ -88,7 +88,7 @@ struct ProjParams {
   int N, k_per_split;
   int r, B, S;
   int flags;
-  const StageRec* rec;  // [stages]
+  const StageRec* rec;  // [stages]; handed to the kernel as an argument of its own (see project_fused_kernel)
   const int* any_unwindowed;
 };
 
@@ -174,7 +174,7 @@ __device__ __forceinline__ void block_store(double* out, int r, int i0, int j0, 
 // s+1 are in flight into registers (their addresses come from the stage record fetched during stage s-1, so
 // no load waits on another load); they are written to LDS after the MFMAs of stage s.
 template <int TR, int W, bool MIXED>
-__device__ __forceinline__ void project_wave(const ProjParams& p, double* sm) {
+__device__ __forceinline__ void project_wave(const ProjParams& p, const StageRec* __restrict__ rec, double* sm) {
   constexpr int STRIDE = stride_of(TR);
   constexpr int PAIRS = 8 * TR;                               // d2 pairs per window row
   constexpr int RPP = PT / PAIRS;                             // window rows per pass of the workgroup
@@ -287,8 +287,8 @@ __device__ __forceinline__ void project_wave(const ProjParams& p, double* sm) {
   const int st0 = kbeg / PK, st1 = (kend + PK - 1) / PK;
   StageRec r1{}, r2{};
   if (st0 < st1) {
-    r1 = p.rec[st0];
-    if (st0 + 1 < st1) r2 = p.rec[st0 + 1];
+    r1 = rec[st0];
+    if (st0 + 1 < st1) r2 = rec[st0 + 1];
     fetch(kbeg, r1);
     commit(r1);
   }
@@ -304,7 +304,7 @@ __device__ __forceinline__ void project_wave(const ProjParams& p, double* sm) {
     const bool more = st + 1 < st1;
     if (more) {
       r1 = r2;                                    // loaded one stage ago
-      if (st + 2 < st1) r2 = p.rec[st + 2];       // for the next iteration
+      if (st + 2 < st1) r2 = rec[st + 2];       // for the next iteration
       if (!PF_ABLATE(64)) fetch(k0 + PK, r1);
     }
     // B operand: rows of A_b V.  The entries of a row are taken U at a time: U entry reads, then their U TR
@@ -405,8 +405,12 @@ __device__ __forceinline__ void project_wave(const ProjParams& p, double* sm) {
 // stage s (with it, a vmcnt(0) lands in front of the MFMAs).  Both variants are launched; the one the table's
 // header does not ask for returns at once, so the host never has to read the header back.
 template <int TR, bool MIXED>
-__global__ __launch_bounds__(PT, TR <= 5 ? 4 : 2) void project_fused_kernel(const ProjParams p) {
-  if ((*p.any_unwindowed != 0) != MIXED) return;
+__global__ __launch_bounds__(PT, TR <= 5 ? 4 : 2) void project_fused_kernel(const ProjParams p, const StageRec* __restrict__ rec,
+                                                                            const int* __restrict__ any_unwindowed) {
+  // rec and the header are arguments of their own: only a __restrict__ kernel argument tells the compiler that
+  // nothing in the kernel writes the table, and only then does it fetch the records with scalar loads (through
+  // the struct it used a vector load + vmcnt(0) + readfirstlane at the head of every stage)
+  if ((*any_unwindowed != 0) != MIXED) return;
   extern __shared__ __attribute__((aligned(16))) double sm[];
   // a short last stage lets the A operand reach rows past the window (they only meet zero rows of B, but must be
   // finite): no LDS word is ever read uninitialised; the entries behind the staged ones stay zero
@@ -414,14 +418,14 @@ __global__ __launch_bounds__(PT, TR <= 5 ? 4 : 2) void project_fused_kernel(cons
   for (int i = threadIdx.x; i < words; i += PT) sm[i] = 0.0;
   __syncthreads();
   switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {  // one code path per wave: its tiles are constants
-    case 0: project_wave<TR, 0, MIXED>(p, sm); break;
-    case 1: project_wave<TR, 1, MIXED>(p, sm); break;
-    case 2: project_wave<TR, 2, MIXED>(p, sm); break;
-    case 3: project_wave<TR, 3, MIXED>(p, sm); break;
-    case 4: project_wave<TR, 4, MIXED>(p, sm); break;
-    case 5: project_wave<TR, 5, MIXED>(p, sm); break;
-    case 6: project_wave<TR, 6, MIXED>(p, sm); break;
-    default: project_wave<TR, 7, MIXED>(p, sm); break;
+    case 0: project_wave<TR, 0, MIXED>(p, rec, sm); break;
+    case 1: project_wave<TR, 1, MIXED>(p, rec, sm); break;
+    case 2: project_wave<TR, 2, MIXED>(p, rec, sm); break;
+    case 3: project_wave<TR, 3, MIXED>(p, rec, sm); break;
+    case 4: project_wave<TR, 4, MIXED>(p, rec, sm); break;
+    case 5: project_wave<TR, 5, MIXED>(p, rec, sm); break;
+    case 6: project_wave<TR, 6, MIXED>(p, rec, sm); break;
+    default: project_wave<TR, 7, MIXED>(p, rec, sm); break;
   }
 }
 
@@ -485,8 +489,8 @@ static int fused_blocks_per_cu(rt_ctx* ctx, int tr, int* out) {
 
 template <int TR>
 static int launch_fused(rt_ctx* ctx, const ProjParams& p, unsigned grid) {
-  hipLaunchKernelGGL((project_fused_kernel<TR, false>), dim3(grid), dim3(PT), fused_lds<TR>(), ctx->stream, p);
-  hipLaunchKernelGGL((project_fused_kernel<TR, true>), dim3(grid), dim3(PT), fused_lds<TR>(), ctx->stream, p);
+  hipLaunchKernelGGL((project_fused_kernel<TR, false>), dim3(grid), dim3(PT), fused_lds<TR>(), ctx->stream, p, p.rec, p.any_unwindowed);
+  hipLaunchKernelGGL((project_fused_kernel<TR, true>), dim3(grid), dim3(PT), fused_lds<TR>(), ctx->stream, p, p.rec, p.any_unwindowed);
   RT_HIP_CHECK(ctx, hipGetLastError());
   return RT_OK;
 }
