@@ -16,6 +16,8 @@ LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libromtime_hip.so")
 SOURCES = ["api.hip", "gemm_mfma.hip", "tallskinny.hip", "rank_update.hip", "gram_mfma.hip", "deim.hip", "sparse.hip", "project_fused.hip", "solve.hip", "sweep.hip", "symeig.hip", "host_dense.cpp", "p1_assembly.hip", "pod_orth.hip"]
 FLAGS = ["-O3", "--offload-arch=gfx950", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# measurement builds only, e.g. ROMTIME_EXTRA_HIPFLAGS=-DROMTIME_PF_ABLATE (timing switches of csrc/project_fused.hip)
+FLAGS += os.environ.get("ROMTIME_EXTRA_HIPFLAGS", "").split()
 
 
 def _hipcc():

@@ -25,11 +25,18 @@
 #include <cstdlib>
 #include <type_traits>
 
-// Timing-only builds (-DROMTIME_PF_ABLATE, then ROMTIME_PF_FLAGS = 8: no buffer-descriptor fetch, 16: no gather,
-// 32: no MFMAs, 64: no global loads) price the phases of a stage; their results are wrong by design, so the
-// switches do not exist in the shipped library.  Measured (32 vectors, N = 1e5, r = 80, ms): all 0.98 = skeleton
-// (barriers, commit, scalar code) 0.19 + MFMAs 0.57 + gather 0.17 + fetch 0.07 - the phases of the two workgroups
-// a CU holds add up rather than overlap; one workgroup per CU takes 1.39.
+// Timing-only builds (ROMTIME_EXTRA_HIPFLAGS=-DROMTIME_PF_ABLATE python -m romtime_amd.build, then ROMTIME_PF_FLAGS =
+// 8: no buffer-descriptor fetch, 16: no gather, 32: no MFMAs, 64: no global loads, 16384: time stamps around the
+// MFMA phases) price the phases of a stage; their results are wrong by design, so the switches do not exist in the
+// shipped library.  Measured (32 vectors, N = 1e5, r = 80, ms): all 0.89 = skeleton (barriers, commit, scalar code)
+// 0.18 + MFMAs 0.55 (the matrix-core time of the flops at the clock the chip holds) + gather 0.14 + fetch 0.02.
+// The two workgroups a CU holds do run half a stage apart (time stamps: MFMA phase 4300 of a 10400-cycle stage,
+// the second workgroup's 0.57 of a period behind the first's; a deliberate skew, a rotation of the heavy SIMD and
+// a 1024-thread workgroup of two groups sharing barriers one phase apart changed nothing or lost), but the vector
+// instructions of the other phases queue behind the 64-cycle MFMAs of the neighbour, so those phases stretch to
+// 6100 cycles and the matrix cores idle 30 % of the time.  Every vector instruction outside the MFMA phase costs
+// latency as well as issue time; that is what the stage loads through buffer descriptors, the affine window copy
+// and the chunked gather are for.
 #ifdef ROMTIME_PF_ABLATE
 #define PF_ABLATE(bit) ((p.flags & (bit)) != 0)
 #else
@@ -168,6 +175,12 @@ __device__ __forceinline__ void block_store(double* out, int r, int i0, int j0, 
         }
   }
 }
+
+#ifdef ROMTIME_PF_ABLATE
+// per workgroup: HW_ID | XCC_ID << 32, then s_memtime at the head and tail of the MFMA phases of stages 10..17
+// (ROMTIME_PF_FLAGS & 16384; read back with rt_pf_debug_dump, tools/probes/proj_phase.py)
+__device__ unsigned long long g_dbg[2048 * 20];
+#endif
 
 // The whole stage loop for the wave that owns block W of the layout (compile-time tiles).  Software-pipelined:
 // while stage s is computed out of LDS, the entries, the per-row entry ranges and the V-row window of stage
@@ -366,6 +379,10 @@ __device__ __forceinline__ void project_wave(const ProjParams& p, const StageRec
     }
     __syncthreads();
     __builtin_amdgcn_s_setprio(0);
+#ifdef ROMTIME_PF_ABLATE
+    if (W == 0 && (p.flags & 16384) && blockIdx.x < 2048 && st - st0 >= 10 && st - st0 < 18 && lane == 0)
+      g_dbg[blockIdx.x * 20 + 2 + 2 * (st - st0 - 10)] = __builtin_amdgcn_s_memtime();
+#endif
     if constexpr (NT > 0) if (!PF_ABLATE(32)) {
       // operands of k-step k4 + 1 are read before the MFMAs of k-step k4 are issued
       const double* lA = lA0 + (k0 - c_lo) * STRIDE;  // LDS row of DoF k0 (+ this lane's k)
@@ -391,6 +408,12 @@ __device__ __forceinline__ void project_wave(const ProjParams& p, const StageRec
             acc[i * NJ + j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][i], bq[cur][j], acc[i * NJ + j], 0, 0, 0);
       }
     }
+#ifdef ROMTIME_PF_ABLATE
+    if (W == 0 && (p.flags & 16384) && blockIdx.x < 2048 && st - st0 >= 10 && st - st0 < 18 && lane == 0) {
+      g_dbg[blockIdx.x * 20 + 3 + 2 * (st - st0 - 10)] = __builtin_amdgcn_s_memtime();
+      g_dbg[blockIdx.x * 20] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) << 32);
+    }
+#endif
     __builtin_amdgcn_s_setprio(3);   // gather, fetch and commit phases win the issue slot over the other workgroup's MFMAs
     __syncthreads();
     if (more) commit(r1);
@@ -584,3 +607,9 @@ int rt_project_fused(rt_ctx* ctx, const int64_t* indptr, const int64_t* indices,
   ctx->last_grid = B * S; ctx->last_splits = S; ctx->last_tile = rp * 1000 + rp;
   return RT_OK;
 }
+
+#ifdef ROMTIME_PF_ABLATE
+extern "C" int rt_pf_debug_dump(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * (size_t)n) == hipSuccess ? 0 : -1;
+}
+#endif
