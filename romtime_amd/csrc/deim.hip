@@ -7,12 +7,12 @@
 //                    r_k = phi_k - sum_{j<k} r_j * (y_j / delta_j),   y = L^-1 phi_k[p_<k],
 // with delta_j = r_j[p_j] and L[i][j] = r_j[p_i] / delta_j the unit-lower factor whose
 // multipliers are bounded by 1 because every pivot is the residual's largest entry.  L^-1 is
-// kept explicitly and bordered by one vector-matrix product per step, so a step has no
-// sequential k-long dependency chain: one single-workgroup "pivot" kernel (argmax finish,
-// border, triangular mat-vec) and one chip-wide "residual" kernel that streams k residual
-// columns (16-B coalesced loads, column-major) and reduces |r| to (top1, index, top2) per
-// workgroup with a lexicographic (value desc, index asc) order -- np.argmax's tie rule.
-// HBM traffic is the algorithmic 8 N (k+2) bytes per step.
+// kept explicitly and bordered step by step, so a step has no sequential k-long dependency
+// chain.  Columns are taken in blocks of 8 (see rt_deim_greedy): inside a block a step needs
+// only the block's own 8 x 8 corner of L^-1, which every workgroup of the column's chip-wide
+// kernel works out for itself before it streams the block's residual columns (16-B coalesced
+// loads, column-major) and reduces |r| to (top1, index, top2) per workgroup with a
+// lexicographic (value desc, index asc) order -- np.argmax's tie rule.  One launch per step.
 #include "common.h"
 #include "wave_ops.h"
 
@@ -75,160 +75,239 @@ __device__ __forceinline__ Top2 top2_wave(Top2 t) {  // result valid in lane 63,
   return o;
 }
 
+constexpr int BLK = 8;  // columns per block of the blocked left-looking elimination
 constexpr int RES_THREADS = 256;
-constexpr int RES_ROWS = 2 * RES_THREADS;  // rows per workgroup (one d2 per thread)
+constexpr int RES_ROWS = 2 * RES_THREADS;  // rows per workgroup of the sweeps (one d2 per thread)
+constexpr int COL_ROWS = 4 * RES_THREADS;  // rows per workgroup of a column's kernel (two d2 per thread)
+constexpr int PIV_THREADS = 1024;          // the once-per-block serial kernel
 
-// r_k = R[k] - sum_{j<k} R[j] * yt[j]  (in place in column k);  per-workgroup top-2 of |r_k|.
-__global__ __launch_bounds__(RES_THREADS) void deim_residual_kernel(double* __restrict__ R, long ldr, long N,
-                                                                    int k, int jstart,
-                                                                    const double* __restrict__ yt,
-                                                                    double* __restrict__ pv1,
-                                                                    long* __restrict__ pi1,
-                                                                    double* __restrict__ pv2) {
-  __shared__ double s_yt[1024];
-  __shared__ Top2 s_red[RES_THREADS / 64];
-  const int tid = threadIdx.x;
-  for (int j = jstart + tid; j < k; j += RES_THREADS) s_yt[j] = yt[j];
-  __syncthreads();
-  const long row = (long)blockIdx.x * RES_ROWS + 2 * tid;
-  Top2 best{-1.0, 0x7fffffffffffffffL, -1.0};
-  if (row < N) {  // ldr is even and columns are padded, so the pair (row, row+1) is always addressable
-    d2 acc{0.0, 0.0};
-    const double* col = R + row;
-    int j = jstart;
-    for (; j + 4 <= k; j += 4) {
-      const d2 a0 = *reinterpret_cast<const d2*>(col + (long)(j + 0) * ldr);
-      const d2 a1 = *reinterpret_cast<const d2*>(col + (long)(j + 1) * ldr);
-      const d2 a2 = *reinterpret_cast<const d2*>(col + (long)(j + 2) * ldr);
-      const d2 a3 = *reinterpret_cast<const d2*>(col + (long)(j + 3) * ldr);
-      const double y0 = s_yt[j], y1 = s_yt[j + 1], y2 = s_yt[j + 2], y3 = s_yt[j + 3];
-      acc.x = fma(a0.x, y0, acc.x); acc.y = fma(a0.y, y0, acc.y);
-      acc.x = fma(a1.x, y1, acc.x); acc.y = fma(a1.y, y1, acc.y);
-      acc.x = fma(a2.x, y2, acc.x); acc.y = fma(a2.y, y2, acc.y);
-      acc.x = fma(a3.x, y3, acc.x); acc.y = fma(a3.y, y3, acc.y);
-    }
-    for (; j < k; ++j) {
-      const d2 a = *reinterpret_cast<const d2*>(col + (long)j * ldr);
-      const double y = s_yt[j];
-      acc.x = fma(a.x, y, acc.x);
-      acc.y = fma(a.y, y, acc.y);
-    }
-    d2* dst = reinterpret_cast<d2*>(R + (long)k * ldr + row);
-    d2 r = *dst;
-    r.x -= acc.x;
-    r.y -= acc.y;
-    *dst = r;
-    const double ax = fabs(r.x), ay = (row + 1 < N) ? fabs(r.y) : -1.0;
-    Top2 t0{ax, row, -1.0}, t1{ay, row + 1, -1.0};
-    best = top2_merge(t0, t1);
+struct StepState {   // what a step leaves behind, all in device memory
+  int m, nparts;
+  double* pv1;   // per-workgroup (top1, index, top2) of the newest residual column
+  long* pi1;
+  double* pv2;
+  long* idx;
+  double* delta;
+  double* margin;
+  double* Linv;  // [m][m] row-major, zero above the diagonal
+};
+
+struct StepShared {
+  Top2 red[PIV_THREADS / 64];
+  double lin[BLK][BLK + 1];   // the block's own corner of L^-1
+  double del[BLK];
+  long pidx[BLK];
+  double l[BLK];
+  double b[BLK];
+  double yt[BLK];
+  long p;
+  double v1, v2;
+};
+
+// Finish step kp (kp >= jstart, the first column of its block) with T threads, every thread of every workgroup that
+// calls it arriving at the same numbers: the argmax over the workgroup partials of residual kp -> p; delta = r_kp[p];
+// the block's corner of row kp of L^-1 (l_i = r_i[p] / delta_i for the block's earlier columns i); and, when `k` =
+// kp + 1 is in the same block, the coefficients yt_i (i = jstart..kp) of column k against the block's columns -
+// column k of R holds t_k, already reduced by the columns before the block.  Everything here is at most BLK x BLK:
+// the part of row kp of L^-1 that lies before the block is not needed until the next block starts
+// (deim_block_start_kernel).  `persist`: this caller writes idx, delta, margin and the row's corner to memory.
+template <int T>
+__device__ __forceinline__ void deim_finish_step(const double* R, long ldr, int kp, int jstart, bool want_yt,
+                                                 bool persist, const StepState& a, StepShared& sh) {
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int m = a.m, n = kp - jstart;   // earlier columns of the block
+  // corner of L^-1, deltas and indices of the block's earlier columns: independent of the new pivot
+  if (tid < BLK * BLK) {
+    const int i = tid / BLK, j = tid % BLK;
+    sh.lin[i][j] = (i < n && j <= i) ? a.Linv[(long)(jstart + i) * m + jstart + j] : 0.0;
   }
+  if (tid < n) {
+    sh.del[tid] = a.delta[jstart + tid];
+    sh.pidx[tid] = a.idx[jstart + tid];
+  }
+  Top2 best{-1.0, 0x7fffffffffffffffL, -1.0};
+  for (int q = tid; q < a.nparts; q += T) best = top2_merge(best, Top2{a.pv1[q], a.pi1[q], a.pv2[q]});
   best = top2_wave(best);
-  if ((tid & 63) == 0) s_red[tid >> 6] = best;
+  if (lane == 0) sh.red[wid] = best;
   __syncthreads();
   if (tid == 0) {
-    Top2 t = s_red[0];
-    for (int w = 1; w < RES_THREADS / 64; ++w) t = top2_merge(t, s_red[w]);
-    pv1[blockIdx.x] = t.v1;
-    pi1[blockIdx.x] = t.i1;
-    pv2[blockIdx.x] = t.v2;
+    Top2 t = sh.red[0];
+    for (int w = 1; w < T / 64; ++w) t = top2_merge(t, sh.red[w]);
+    sh.p = t.i1;
+    sh.v1 = t.v1;
+    sh.v2 = t.v2;
+  }
+  __syncthreads();
+  const long p = sh.p;
+  if (tid < n) sh.l[tid] = R[(long)(jstart + tid) * ldr + p] / sh.del[tid];
+  if (tid == n) {
+    sh.del[n] = R[(long)kp * ldr + p];
+    sh.pidx[n] = p;
+  }
+  if (want_yt && tid >= 64 && tid - 64 <= n) {   // t_k at the block's pivot rows
+    const int j = tid - 64;
+    sh.b[j] = R[(long)(kp + 1) * ldr + (j < n ? sh.pidx[j] : p)];
+  }
+  __syncthreads();
+  // row kp of the corner:  Linv[kp][j] = -sum_{i=j}^{kp-1} l_i Linv[i][j],  Linv[kp][kp] = 1
+  if (tid <= n) {
+    double acc = 0.0;
+    for (int i = tid; i < n; ++i) acc = fma(sh.l[i], sh.lin[i][tid], acc);
+    sh.lin[n][tid] = (tid == n) ? 1.0 : -acc;
+  }
+  __syncthreads();
+  if (want_yt && tid <= n) {   // y_i = sum_{j<=i} Linv[i][j] t_k[p_j],  yt_i = y_i / delta_i
+    double acc = 0.0;
+    for (int j = 0; j <= tid; ++j) acc = fma(sh.lin[tid][j], sh.b[j], acc);
+    sh.yt[tid] = acc / sh.del[tid];
+  }
+  if (persist) {
+    if (tid <= n) a.Linv[(long)kp * m + jstart + tid] = sh.lin[n][tid];
+    if (tid == 0) {
+      a.idx[kp] = p;
+      a.delta[kp] = sh.del[n];
+      if (a.margin) a.margin[kp] = (sh.v1 > 0.0) ? (sh.v1 - fmax(sh.v2, 0.0)) / sh.v1 : 0.0;
+    }
+  }
+  __syncthreads();
+}
+
+// Column k of a block: first every workgroup finishes step k - 1 for itself (deim_finish_step: the numbers are
+// small and all in the L2; doing it here instead of in a single-workgroup kernel between two chip-wide ones takes
+// the 9 us "pivot" launch out of every step), then
+//   r_k = R[k] - sum_{jstart<=j<k} R[j] * yt[j]  (in place in column k)  and the per-workgroup top-2 of |r_k|.
+__global__ __launch_bounds__(RES_THREADS) void deim_column_kernel(double* R, long ldr, long N, int k, int jstart,
+                                                                  StepState st) {
+  __shared__ StepShared sh;
+  const int tid = threadIdx.x;
+  const int nj = k - jstart;   // < BLK
+  constexpr int H = COL_ROWS / RES_ROWS;
+  // the column's own loads do not depend on the step before: they are in flight while it is finished
+  d2 av[H][BLK - 1], rv[H];
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    const long row = (long)blockIdx.x * COL_ROWS + h * RES_ROWS + 2 * tid;
+    rv[h] = d2{0.0, 0.0};
+#pragma unroll
+    for (int j = 0; j < BLK - 1; ++j) av[h][j] = d2{0.0, 0.0};
+    if (row < N) {  // ldr is even and columns are padded, so the pair (row, row+1) is always addressable
+      const double* col = R + row + (long)jstart * ldr;
+#pragma unroll
+      for (int j = 0; j < BLK - 1; ++j)
+        if (j < nj) av[h][j] = *reinterpret_cast<const d2*>(col + (long)j * ldr);
+      rv[h] = *reinterpret_cast<const d2*>(R + (long)k * ldr + row);
+    }
+  }
+  if (nj > 0) deim_finish_step<RES_THREADS>(R, ldr, k - 1, jstart, true, blockIdx.x == 0, st, sh);
+  Top2 best{-1.0, 0x7fffffffffffffffL, -1.0};
+#pragma unroll
+  for (int h = 0; h < H; ++h) {
+    const long row = (long)blockIdx.x * COL_ROWS + h * RES_ROWS + 2 * tid;
+    if (row < N) {
+      d2 acc{0.0, 0.0};
+#pragma unroll
+      for (int j = 0; j < BLK - 1; ++j) {
+        if (j < nj) {
+          const double y = sh.yt[j];
+          acc.x = fma(av[h][j].x, y, acc.x);
+          acc.y = fma(av[h][j].y, y, acc.y);
+        }
+      }
+      d2 r = rv[h];
+      r.x -= acc.x;
+      r.y -= acc.y;
+      *reinterpret_cast<d2*>(R + (long)k * ldr + row) = r;
+      const double ax = fabs(r.x), ay = (row + 1 < N) ? fabs(r.y) : -1.0;
+      best = top2_merge(best, top2_merge(Top2{ax, row, -1.0}, Top2{ay, row + 1, -1.0}));
+    }
+  }
+  best = top2_wave(best);
+  __syncthreads();   // sh.red is free again
+  if ((tid & 63) == 0) sh.red[tid >> 6] = best;
+  __syncthreads();
+  if (tid == 0) {
+    Top2 t = sh.red[0];
+    for (int w = 1; w < RES_THREADS / 64; ++w) t = top2_merge(t, sh.red[w]);
+    st.pv1[blockIdx.x] = t.v1;
+    st.pi1[blockIdx.x] = t.i1;
+    st.pv2[blockIdx.x] = t.v2;
   }
 }
 
-constexpr int PIV_THREADS = 1024;
-
-// Runs between residual kernels.  `k` = the step whose coefficients are prepared (k >= 1);
-// first finishes step k-1: idx[k-1], delta[k-1], margin[k-1], row k-1 of L^-1.
-// With k == m only the finish part runs.
-__global__ __launch_bounds__(PIV_THREADS) void deim_pivot_kernel(const double* __restrict__ R, long ldr, int k,
-                                                                 int jstart, int m, int nparts, const double* __restrict__ pv1,
-                                                                 const long* __restrict__ pi1,
-                                                                 const double* __restrict__ pv2, long* idx,
-                                                                 double* delta, double* margin, double* Linv,
-                                                                 double* yt) {
-  __shared__ Top2 s_red[PIV_THREADS / 64];
-  __shared__ double s_l[1024];
-  __shared__ double s_b[1024];
-  __shared__ double s_part[PIV_THREADS];
-  __shared__ long s_p;
+// Once per block, one workgroup, k0 = first column of the block that starts (k0 = m: nothing starts):
+//   a. finish the last step of the block before (deim_finish_step), whose columns are P = [kb, k0);
+//   b. the rows P of L^-1 before column kb, which no step inside P needed:
+//        W = L21 Linv[:kb,:kb],  L21[i][q] = r_q[p_i] / delta_q  (i in P, q < kb),
+//        Linv[i][j] = -(W[i][j] + sum_{q in P, q < i} l_iq Linv[q][j])   (the step-by-step recurrence, row by row);
+//   c. coefficients of the new block's columns against everything before it:
+//        YT[c - k0][i] = (Linv[:k0,:k0] b_c)_i / delta_i,   b_c[i] = phi_c[p_i]   (column c of R still holds phi_c).
+__global__ __launch_bounds__(PIV_THREADS) void deim_block_start_kernel(const double* R, long ldr, int k0, int kb, int nb,
+                                                                       StepState st, double* __restrict__ YT) {
+  constexpr int CG = 4;  // columns per pass over L^-1 (each row of L^-1 is read once per pass)
+  __shared__ StepShared sh;
+  __shared__ double s_b[BLK][1024];      // phase b: partial sums of W; phase c: rows [0, CG) = b_c
+  __shared__ double s_l21[BLK][1024];
+  __shared__ double s_l22[BLK][BLK];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int kp = k - 1;  // step being finished
-
-  // 1. final argmax over the workgroup partials of residual kp
-  Top2 best{-1.0, 0x7fffffffffffffffL, -1.0};
-  for (int q = tid; q < nparts; q += PIV_THREADS) best = top2_merge(best, Top2{pv1[q], pi1[q], pv2[q]});
-  best = top2_wave(best);
-  if (lane == 0) s_red[wid] = best;
-  __syncthreads();
-  if (tid == 0) {
-    Top2 t = s_red[0];
-    for (int w = 1; w < PIV_THREADS / 64; ++w) t = top2_merge(t, s_red[w]);
-    s_p = t.i1;
-    idx[kp] = t.i1;
-    delta[kp] = R[(long)kp * ldr + t.i1];
-    if (margin) margin[kp] = (t.v1 > 0.0) ? (t.v1 - fmax(t.v2, 0.0)) / t.v1 : 0.0;
-  }
-  __syncthreads();
-  const long p = s_p;
-
-  // 2. border L^-1 with row kp:  l_j = r_j[p] / delta_j (j < kp);  Linv[kp][:] = -l^T Linv, Linv[kp][kp] = 1.
-  //    Eight threads share a column (rows i == part mod 8), so nobody walks more than kp/8 entries of the
-  //    column-strided Linv; the partial sums meet in LDS and are added in a fixed order.
-  for (int j = tid; j < kp; j += PIV_THREADS) s_l[j] = R[(long)j * ldr + p] / delta[j];
-  __syncthreads();
-  {
-    const int jj = tid & 127, part = tid >> 7;
-    for (int j0 = 0; j0 < kp; j0 += 128) {
-      const int j = j0 + jj;
-      double acc = 0.0;
-      if (j < kp) {
-#pragma unroll 4
-        for (int i = j + part; i < kp; i += PIV_THREADS / 128) acc = fma(s_l[i], Linv[(long)i * m + j], acc);
-      }
-      s_part[part * 128 + jj] = acc;
-      __syncthreads();
-      if (part == 0 && j < kp) {
-        double sum = 0.0;
-#pragma unroll
-        for (int q = 0; q < PIV_THREADS / 128; ++q) sum += s_part[q * 128 + jj];
-        Linv[(long)kp * m + j] = -sum;
-      }
-      __syncthreads();
-    }
-  }
-  if (tid == 0) Linv[(long)kp * m + kp] = 1.0;
-  if (k >= m) return;
+  const int m = st.m, np = k0 - kb;
+  deim_finish_step<PIV_THREADS>(R, ldr, k0 - 1, kb, false, true, st, sh);
   __threadfence_block();
   __syncthreads();
-
-  // 3. in-block coefficients: column k of R holds t_k (already reduced by the columns before the block,
-  //    see deim_phase_a_kernel), so  y_i = sum_{jstart<=j<=i} Linv[i][j] t_k[p_j]  and  yt_i = y_i / delta_i
-  for (int i = jstart + tid; i < k; i += PIV_THREADS) s_b[i] = R[(long)k * ldr + idx[i]];
-  __syncthreads();
-  for (int i = jstart + wid; i < k; i += PIV_THREADS / 64) {
-    double acc = 0.0;
-    for (int j = jstart + lane; j <= i; j += 64) acc = fma(Linv[(long)i * m + j], s_b[j], acc);
-    acc = rtw::wave_sum(acc);
-    if (lane == 0) yt[i] = acc / delta[i];
+  if (kb > 0 && k0 < m) {   // (after the last block nobody reads L^-1 again)
+    for (int q = tid; q < np * kb; q += PIV_THREADS) {
+      const int i = q / kb, c = q % kb;
+      s_l21[i][c] = R[(long)c * ldr + st.idx[kb + i]] / st.delta[c];
+    }
+    if (tid < BLK * BLK) {
+      const int i = tid / BLK, q = tid % BLK;   // l_iq for q in P, q < i
+      s_l22[i][q] = (i < np && q < i) ? R[(long)(kb + q) * ldr + st.idx[kb + i]] / st.delta[kb + q] : 0.0;
+    }
+    __syncthreads();
+    // W = L21 Linv[:kb,:kb]: eight threads share a column j (rows q == part mod 8 of the walk down L^-1, coalesced
+    // across j), their partial sums meet in LDS and are added in a fixed order; then the block's own rows in turn
+    constexpr int PARTS = PIV_THREADS / 128;
+    double(*s_w)[BLK][128] = reinterpret_cast<double(*)[BLK][128]>(&s_b[0][0]);   // [PARTS][BLK][128] = 64 KB
+    const int jj = tid & 127, part = tid >> 7;
+    for (int j0 = 0; j0 < kb; j0 += 128) {
+      const int j = j0 + jj;
+      double w[BLK];
+#pragma unroll
+      for (int i = 0; i < BLK; ++i) w[i] = 0.0;
+      if (j < kb) {
+#pragma unroll 4
+        for (int q = j + part; q < kb; q += PARTS) {
+          const double lq = st.Linv[(long)q * m + j];
+#pragma unroll
+          for (int i = 0; i < BLK; ++i) w[i] = fma(s_l21[i][q], lq, w[i]);
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < BLK; ++i) s_w[part][i][jj] = w[i];
+      __syncthreads();
+      if (part == 0 && j < kb) {
+        double out[BLK];
+#pragma unroll
+        for (int i = 0; i < BLK; ++i) {
+          double acc = 0.0;
+#pragma unroll
+          for (int q = 0; q < PARTS; ++q) acc += s_w[q][i][jj];
+#pragma unroll
+          for (int q = 0; q < BLK; ++q)
+            if (q < i) acc = fma(s_l22[i][q], out[q], acc);
+          out[i] = -acc;
+          if (i < np) st.Linv[(long)(kb + i) * m + j] = out[i];
+        }
+      }
+      __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
   }
-}
-
-constexpr int BLK = 8;  // columns per block of the blocked left-looking elimination
-
-// Coefficients of a block of columns against everything before the block:
-//   YT[c - k0][i] = (Linv[:k0,:k0] b_c)_i / delta_i,   b_c[i] = phi_c[p_i]   (i < k0, c in the block)
-// Column c of R still holds phi_c when this runs.
-__global__ __launch_bounds__(PIV_THREADS) void deim_block_coeff_kernel(const double* __restrict__ R, long ldr, int k0,
-                                                                       int nb, int m, const long* __restrict__ idx,
-                                                                       const double* __restrict__ delta,
-                                                                       const double* __restrict__ Linv,
-                                                                       double* __restrict__ YT) {
-  constexpr int CG = 4;  // columns per pass over L^-1 (each row of L^-1 is read once per pass)
-  __shared__ double s_b[CG][1024];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  if (k0 >= m) return;
   for (int c0 = 0; c0 < nb; c0 += CG) {
     __syncthreads();
     for (int i = tid; i < k0; i += PIV_THREADS) {
-      const long p = idx[i];
+      const long p = st.idx[i];
 #pragma unroll
       for (int c = 0; c < CG; ++c) s_b[c][i] = (c0 + c < nb) ? R[(long)(k0 + c0 + c) * ldr + p] : 0.0;
     }
@@ -238,11 +317,11 @@ __global__ __launch_bounds__(PIV_THREADS) void deim_block_coeff_kernel(const dou
 #pragma unroll
       for (int c = 0; c < CG; ++c) acc[c] = 0.0;
       for (int j = lane; j <= i; j += 64) {
-        const double l = Linv[(long)i * m + j];
+        const double l = st.Linv[(long)i * m + j];
 #pragma unroll
         for (int c = 0; c < CG; ++c) acc[c] = fma(l, s_b[c][j], acc[c]);
       }
-      const double di = delta[i];
+      const double di = st.delta[i];
 #pragma unroll
       for (int c = 0; c < CG; ++c) {
         const double sum = rtw::wave_sum(acc[c]);
@@ -336,29 +415,26 @@ extern "C" int rt_deim_greedy(rt_ctx* ctx, const double* Phi, int64_t N, int64_t
   RT_ARG_CHECK(ctx, ld >= (layout == RT_COL_MAJOR ? N : m));
 
   const long ldr = (N + 15) / 16 * 16;
-  const int nparts = (int)((N + RES_ROWS - 1) / RES_ROWS);
-  // scratch: R | Linv | yt | delta | pv1 | pv2 | pi1
+  const int nparts = (int)((N + RES_ROWS - 1) / RES_ROWS);   // workgroups of the block sweeps
+  const int ncol = (int)((N + COL_ROWS - 1) / COL_ROWS);     // workgroups (= argmax partials) of a column's kernel
+  // scratch: R | Linv | delta | YT | pv1 | pv2 | pi1
   size_t off = 0;
   auto take = [&off](size_t bytes) {
     size_t o = off;
     off += (bytes + 255) / 256 * 256;
     return o;
   };
-  const size_t oR = take(sizeof(double) * ldr * m), oL = take(sizeof(double) * m * m), oY = take(sizeof(double) * m),
-               oD = take(sizeof(double) * m), oYT = take(sizeof(double) * BLK * m), oV1 = take(sizeof(double) * nparts),
-               oV2 = take(sizeof(double) * nparts), oI1 = take(sizeof(long) * nparts);
+  const size_t oR = take(sizeof(double) * ldr * m), oL = take(sizeof(double) * m * m), oD = take(sizeof(double) * m),
+               oYT = take(sizeof(double) * BLK * m), oV1 = take(sizeof(double) * ncol),
+               oV2 = take(sizeof(double) * ncol), oI1 = take(sizeof(long) * ncol);
   void* base = nullptr;
   int rc = rt_scratch2(ctx, off, &base);
   if (rc != RT_OK) return rc;
   char* b8 = static_cast<char*>(base);
   double* R = reinterpret_cast<double*>(b8 + oR);
   double* Linv = reinterpret_cast<double*>(b8 + oL);
-  double* yt = reinterpret_cast<double*>(b8 + oY);
   double* delta = reinterpret_cast<double*>(b8 + oD);
   double* YT = reinterpret_cast<double*>(b8 + oYT);
-  double* pv1 = reinterpret_cast<double*>(b8 + oV1);
-  double* pv2 = reinterpret_cast<double*>(b8 + oV2);
-  long* pi1 = reinterpret_cast<long*>(b8 + oI1);
   hipStream_t st = ctx->stream;
 
   RT_HIP_CHECK(ctx, hipMemsetAsync(Linv, 0, sizeof(double) * m * m, st));
@@ -371,31 +447,27 @@ extern "C" int rt_deim_greedy(rt_ctx* ctx, const double* Phi, int64_t N, int64_t
   }
   RT_HIP_CHECK(ctx, hipGetLastError());
 
-  // Blocked left-looking elimination: per block of BLK columns one sweep (phase A) applies all earlier
-  // residual columns, then the columns of the block are finished one by one against at most BLK-1
-  // in-block columns.  HBM traffic drops from ~4 N m^2 to ~4 N m^2 / BLK + 4 N m (BLK + 7) bytes.
-  long* idxp = reinterpret_cast<long*>(idx);
+  // Blocked left-looking elimination: per block of BLK columns one serial kernel (finish the block before, block
+  // coefficients) and one sweep (phase A) that applies all earlier residual columns, then one launch per column:
+  // the column's kernel finishes the step before it in every workgroup and reduces the column against at most
+  // BLK-1 in-block columns.  HBM traffic drops from ~4 N m^2 to ~4 N m^2 / BLK + 4 N m (BLK + 7) bytes.
+  const StepState state{(int)m, ncol, reinterpret_cast<double*>(b8 + oV1), reinterpret_cast<long*>(b8 + oI1),
+                        reinterpret_cast<double*>(b8 + oV2), reinterpret_cast<long*>(idx), delta, margin, Linv};
   RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&deim_phase_a_kernel), 1024 * BLK * 8));
   for (int k0 = 0; k0 < (int)m; k0 += BLK) {
     const int nb = ((int)m - k0 < BLK) ? (int)m - k0 : BLK;
     if (k0 > 0) {
-      hipLaunchKernelGGL(deim_pivot_kernel, dim3(1), dim3(PIV_THREADS), 0, st, R, ldr, k0, k0, (int)m, nparts, pv1,
-                         pi1, pv2, idxp, delta, margin, Linv, yt);
-      hipLaunchKernelGGL(deim_block_coeff_kernel, dim3(1), dim3(PIV_THREADS), 0, st, R, ldr, k0, nb, (int)m, idxp,
-                         delta, Linv, YT);
+      hipLaunchKernelGGL(deim_block_start_kernel, dim3(1), dim3(PIV_THREADS), 0, st, R, ldr, k0, k0 - BLK, nb, state, YT);
       hipLaunchKernelGGL(deim_phase_a_kernel, dim3(nparts), dim3(RES_THREADS), sizeof(double) * k0 * BLK, st, R, ldr,
                          (long)N, k0, nb, (int)m, YT);
     }
-    for (int k = k0; k < k0 + nb; ++k) {
-      if (k > k0)
-        hipLaunchKernelGGL(deim_pivot_kernel, dim3(1), dim3(PIV_THREADS), 0, st, R, ldr, k, k0, (int)m, nparts, pv1,
-                           pi1, pv2, idxp, delta, margin, Linv, yt);
-      hipLaunchKernelGGL(deim_residual_kernel, dim3(nparts), dim3(RES_THREADS), 0, st, R, ldr, (long)N, k, k0, yt,
-                         pv1, pi1, pv2);
-    }
+    for (int k = k0; k < k0 + nb; ++k)
+      hipLaunchKernelGGL(deim_column_kernel, dim3(ncol), dim3(RES_THREADS), 0, st, R, ldr, (long)N, k, k0, state);
   }
-  hipLaunchKernelGGL(deim_pivot_kernel, dim3(1), dim3(PIV_THREADS), 0, st, R, ldr, (int)m, (int)m, (int)m, nparts,
-                     pv1, pi1, pv2, idxp, delta, margin, Linv, yt);
+  {  // the last step
+    const int kb = ((int)m - 1) / BLK * BLK;
+    hipLaunchKernelGGL(deim_block_start_kernel, dim3(1), dim3(PIV_THREADS), 0, st, R, ldr, (int)m, kb, 0, state, YT);
+  }
   RT_HIP_CHECK(ctx, hipGetLastError());
   if (PT_U) {
     hipLaunchKernelGGL(deim_gather_ptu_kernel, dim3((unsigned)m), dim3(128), 0, st, Phi, (long)ld, layout, (int)m,
