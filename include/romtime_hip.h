@@ -55,7 +55,7 @@ int rt_ctx_set_profile(rt_ctx* ctx, int on);
  * XCD and hand off through that XCD's L2 (placement is verified on the device); it needs every CU of that XCD,
  * so processes that share a GPU turn it off (a hand-off timeout of rt_sym_eig_values is the symptom).
  * "sweep_graph" (default 0): rt_hrom_bdf_sweep captures one time step as a hipGraph (its kernels read the step from a
- * device counter) and replays it for steps 1 .. nt-1 instead of launching four kernels per step; for hosts that
+ * device counter) and replays it for steps 1 .. nt-1 instead of launching two kernels per step; for hosts that
  * cannot keep ahead of the device.  The call then returns only when the sweep has finished. */
 int rt_ctx_set_option(rt_ctx* ctx, const char* name, int value);
 /* "cu_limit" (default 0 = the device's CU count; a multiple of 8): the number of CUs this ctx sizes its persistent grids
@@ -178,6 +178,16 @@ int rt_project_csr_batched(rt_ctx* ctx, const int64_t* indptr, const int64_t* in
  * K (B x r x r row-major) is left untouched (the factors are not an output), rhs (B x r) is overwritten with x.
  * info (B device ints, may be NULL): 0, or RT_WARN_SINGULAR. r <= 128. */
 int rt_dense_solve_batched(rt_ctx* ctx, double* K, double* rhs, int64_t r, int64_t B, int* info);
+
+/* The same solve for a SEQUENCE of slowly changing matrices (the reduced systems of consecutive time steps differ by
+ * O(dt)): K_b^-1 is tracked in Xinv (B x r x r, caller-owned device memory carried from call to call) and refreshed by
+ * Newton-Schulz iterations on the matrix cores, x = Xinv b plus one step of iterative refinement against K; the first
+ * call (have_prev = 0), a matrix that moved too far, or one the iteration gives up on (singular to working precision:
+ * then pivoted LU inside the same kernel) cost more, the answers agree with rt_dense_solve_batched to rounding.  This is
+ * what rt_rom_bdf_sweep / rt_hrom_bdf_sweep call every step.  info as above.  r <= 80 (three padded matrices in LDS):
+ * RT_ERR_UNSUPPORTED beyond.  rt_ctx_get_counter("sweep_lu_fallbacks" | "sweep_restarts" | ...) tells what happened. */
+int rt_tracked_solve_batched(rt_ctx* ctx, const double* K, double* Xinv, double* rhs, int64_t r, int64_t B, int have_prev,
+                             int* info);
 
 /* ---- online sweep (RomConstructor*.solve, rom/rom.py:430-555, :877-929) on the device --------- */
 typedef struct {

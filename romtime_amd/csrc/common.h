@@ -114,9 +114,10 @@ struct rt_newton_rhs {  // b = M_N (c0 u^n + c1 u^{n-1}) + dt Zf^T F_rhs, per sy
   const long* ctr = nullptr;  // device step counter: Ff is the table base and the step's rows start at *ctr * ff_stride
   long ff_stride = 0;         // (graph replay of a sweep: the launch parameters cannot carry the step)
 };
+struct rt_advance;  // sweep_advance.h: the hyper-reduced sweep's end-of-step work, run as the tail of the solver kernels
 int rt_newton_solve_batched(rt_ctx* ctx, const double* K, double* Xinv, double* rhs, int64_t r, int64_t B,
-                            int have_prev, int* info, const rt_newton_rhs* recipe = nullptr);
-int rt_dense_solve_batched_if(rt_ctx* ctx, double* K, double* rhs, int64_t r, int64_t B, int* info, const int* only_if);
+                            int have_prev, int* info, const rt_newton_rhs* recipe = nullptr,
+                            const rt_advance* advance = nullptr);
 
 // Fused SpMM + V^T(.) projection (project_fused.hip); RT_ERR_UNSUPPORTED for r > 128.  `stage_table` is the
 // per-pattern table built by rt_project_stage_table (rt_project_stage_table_bytes(N) bytes of device memory), or

@@ -217,6 +217,10 @@ int rt_gemm_strided(rt_ctx* ctx, const double* A, int64_t a_ks, int64_t a_ms, co
   const bool kcb = (b_ks == 1) && !(b_ns == 1 && Nn > 1);
   int mt = tile_units(M), nt = tile_units(Nn);
   if (symmetric) nt = mt;
+  // A product too small to give every CU a tile is latency-bound: narrower tiles, more workgroups (the hyper-reduced
+  // sweep's 64 x 6400 x 280 expansion: 50 tiles of 64 x 128 took 33 us, 200 of 64 x 32 take a third of that)
+  if (!symmetric)
+    while (nt > 1 && ((M + 32 * mt - 1) / (32 * mt)) * ((Nn + 32 * nt - 1) / (32 * nt)) < ctx->num_cus) --nt;
   // tall output with <= 64 columns (POD back-projection, lift of a batch of reduced vectors)
   const bool skinny = !symmetric && Nn <= 64 && M >= 256;
   const int snt = (int)((Nn + 15) / 16);

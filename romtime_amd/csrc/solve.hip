@@ -15,6 +15,7 @@
 //   * back substitution runs in the first wave alone (no barriers).
 #include "common.h"
 #include "wave_ops.h"
+#include "sweep_advance.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -24,26 +25,17 @@ constexpr int SOLVE_THREADS = 256;
 constexpr int SOLVE_WAVES = SOLVE_THREADS / 64;
 constexpr int SOLVE_BATCH = 4;
 
-__global__ __launch_bounds__(SOLVE_THREADS) void dense_solve_kernel(const double* __restrict__ K,
-                                                                    double* __restrict__ rhs, int r, int parts,
-                                                                    int* info, const int* only_if, long* counters) {
-  if (only_if && only_if[blockIdx.x] == 0) return;  // fallback launch: only the systems another solver gave up on
-  if (only_if && threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[RT_CNT_LU_FALLBACK]), 1ull);
-  extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int lda = r | 1;  // odd leading dimension: column walks hit distinct banks
-  double* A = sm;         // r x lda
-  double* b = sm + (size_t)r * lda;
-  __shared__ double s_pv[2][SOLVE_WAVES];
-  __shared__ int s_pi[2][SOLVE_WAVES];
+// LU with partial pivoting of the r x r matrix A (LDS, leading dimension lda, overwritten) and the solve with the
+// right-hand side b (LDS, overwritten); the solution goes to xout (global, r values).  NT threads, all of which must
+// call it; `parts` threads share a row.  Returns 1 when a pivot was exactly zero.  The matrix and b must be in LDS
+// and visible (barrier) on entry; xout is complete after the caller's next barrier.
+template <int NT>
+__device__ __forceinline__ int lu_solve_lds(double* A, int lda, double* b, int r, int parts, double* rb) {
+  constexpr int WAVES = NT / 64;
+  __shared__ double s_pv[2][WAVES];
+  __shared__ int s_pi[2][WAVES];
   __shared__ int s_perm[128];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const double* Kb = K + (size_t)blockIdx.x * r * r;
-  double* rb = rhs + (size_t)blockIdx.x * r;
-  for (int i = wid; i < r; i += SOLVE_WAVES)
-    for (int j = lane; j < r; j += 64) A[i * lda + j] = Kb[i * r + j];
-  for (int e = tid; e < r; e += SOLVE_THREADS) b[e] = rb[e];
-  __syncthreads();
-
   const int row = tid / parts, part = tid - row * parts;
   const bool owner = row < r;
   bool retired = !owner;
@@ -63,7 +55,7 @@ __global__ __launch_bounds__(SOLVE_THREADS) void dense_solve_kernel(const double
     double best = s_pv[c & 1][0];
     int pr = s_pi[c & 1][0];
 #pragma unroll
-    for (int w = 1; w < SOLVE_WAVES; ++w) {
+    for (int w = 1; w < WAVES; ++w) {
       const double ov = s_pv[c & 1][w];
       const int oi = s_pi[c & 1][w];
       if (ov > best || (ov == best && oi < pr)) {
@@ -123,7 +115,32 @@ __global__ __launch_bounds__(SOLVE_THREADS) void dense_solve_kernel(const double
       d1 = n1;
     }
   }
+  return sing;
+}
+
+__global__ __launch_bounds__(SOLVE_THREADS) void dense_solve_kernel(const double* __restrict__ K,
+                                                                    double* __restrict__ rhs, int r, int parts,
+                                                                    int* info, const int* only_if, long* counters,
+                                                                    const rt_advance adv) {
+  if (only_if && only_if[blockIdx.x] == 0) return;  // fallback launch: only the systems another solver gave up on
+  if (only_if && threadIdx.x == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[RT_CNT_LU_FALLBACK]), 1ull);
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int lda = r | 1;  // odd leading dimension: column walks hit distinct banks
+  double* A = sm;         // r x lda
+  double* b = sm + (size_t)r * lda;
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const double* Kb = K + (size_t)blockIdx.x * r * r;
+  double* rb = rhs + (size_t)blockIdx.x * r;
+  for (int i = wid; i < r; i += SOLVE_WAVES)
+    for (int j = lane; j < r; j += 64) A[i * lda + j] = Kb[i * r + j];
+  for (int e = tid; e < r; e += SOLVE_THREADS) b[e] = rb[e];
+  __syncthreads();
+  const int sing = lu_solve_lds<SOLVE_THREADS>(A, lda, b, r, parts, rb);
   if (info && tid == 0) info[blockIdx.x] = sing ? RT_WARN_SINGULAR : 0;
+  if (adv.enabled) {  // the hyper-reduced sweep's end of step for this system (its solver kernel left it alone)
+    __syncthreads();  // rb is complete and visible in this workgroup
+    hsweep_advance_rows(adv, blockIdx.x, r, rhs, 1, b, tid, SOLVE_THREADS);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -164,7 +181,8 @@ __global__ __launch_bounds__(NS_THREADS) void newton_solve_kernel(const double* 
                                                                   double* __restrict__ Xinv,
                                                                   double* __restrict__ rhs, int r, int S,
                                                                   int have_prev, int* __restrict__ info,
-                                                                  const rt_newton_rhs rq, long* counters) {
+                                                                  const rt_newton_rhs rq, long* counters,
+                                                                  const rt_advance adv) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int tr = (r + 15) / 16, rp = tr * 16, ntile = tr * tr;
   double* sK = sm;                    // [rp][S], padded with the identity
@@ -178,29 +196,77 @@ __global__ __launch_bounds__(NS_THREADS) void newton_solve_kernel(const double* 
   double* Xb = Xinv + (size_t)blockIdx.x * r * r;
   double* rb = rhs + (size_t)blockIdx.x * r;
 
-  for (int i = wid; i < rp; i += NS_THREADS / 64)
-    for (int j = lane; j < rp; j += 64) {
-      const bool in = i < r && j < r;
-      const double eye = (i == j) ? 1.0 : 0.0;
-      sK[i * S + j] = in ? Kb[i * r + j] : eye;
-      sX[i * S + j] = (in && have_prev) ? Xb[i * r + j] : eye;
+  // out_i = sum_j A[i][j] v[j] for the r rows of an LDS matrix (A, v, out in LDS; out may not be v): eight lanes
+  // share a row (columns j == lane mod 8) and add up with three butterfly steps, 64 rows per pass of the workgroup.
+  // No LDS scratch: the three padded matrices leave 3 KB of the CU's 160.  (One thread per row walked r LDS round
+  // trips one after the other, four times per solve.)
+  auto matvec = [&](const double* A, const double* v, double* out) {
+    const int sub = lane & 7;
+    for (int i0 = 0; i0 < r; i0 += NS_THREADS / 8) {
+      const int i = i0 + (tid >> 3);
+      double acc = 0.0;
+      if (i < r) {
+        const double* row = A + i * S;
+        for (int j = sub; j < r; j += 8) acc = fma(row[j], v[j], acc);
+      }
+      acc += __shfl_xor(acc, 1);
+      acc += __shfl_xor(acc, 2);
+      acc += __shfl_xor(acc, 4);
+      if (i < r && sub == 0) out[i] = acc;
     }
+    __syncthreads();
+  };
+
+  // K, the carried inverse and (when the right-hand side is formed here) M_N come in together: one round of global
+  // loads, M_N parked in sT until the first product needs the space
+  const double* Mb = rq.MN ? rq.MN + (size_t)blockIdx.x * r * r : nullptr;
+  {
+    // rp <= 80: a wave has at most 10 rows (i = wid + 8 q) of at most 2 x 64 columns.  Fixed trip counts, loads of
+    // half the rows issued before any LDS store: a loop over runtime bounds went load - wait - store twenty times
+    constexpr int QH = 5;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      double kv[QH][2], xv[QH][2], mv[QH][2];
+#pragma unroll
+      for (int q = 0; q < QH; ++q)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int i = wid + 8 * (QH * half + q), j = lane + 64 * c;
+          const bool in = i < r && j < r;
+          const double eye = (i == j) ? 1.0 : 0.0;
+          kv[q][c] = in ? Kb[i * r + j] : eye;
+          xv[q][c] = (in && have_prev) ? Xb[i * r + j] : eye;
+          mv[q][c] = (in && Mb) ? Mb[i * r + j] : 0.0;
+        }
+#pragma unroll
+      for (int q = 0; q < QH; ++q)
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int i = wid + 8 * (QH * half + q), j = lane + 64 * c;
+          if (i < rp && j < rp) {
+            sK[i * S + j] = kv[q][c];
+            sX[i * S + j] = xv[q][c];
+            if (Mb) sT[i * S + j] = mv[q][c];
+          }
+        }
+    }
+  }
   if (rq.MN) {
-    // right-hand side formed here: b = M_N (c0 u^n + c1 u^{n-1}) + dt Zf^T F_rhs (also left in rhs for the fallback)
+    // right-hand side: b = M_N (c0 u^n + c1 u^{n-1}) + dt Zf^T F_rhs (also left in rhs for the fallback); row i is
+    // thread i's: r FMAs out of LDS and mf independent loads - a wave per row with a cross-lane sum took a chain
+    // of r / 8 global round trips per wave
     if (tid < r) s_vec[1][tid] = rq.c0 * rq.un[(size_t)blockIdx.x * r + tid] + rq.c1 * rq.unm1[(size_t)blockIdx.x * r + tid];
     __syncthreads();
-    const double* Mb = rq.MN + (size_t)blockIdx.x * r * r;
-    const double* Ff = rq.ctr ? rq.Ff + *rq.ctr * rq.ff_stride : rq.Ff;
-    for (int i = wid; i < r; i += NS_THREADS / 64) {
-      double acc = 0.0;
-      for (int j = lane; j < r; j += 64) acc = fma(Mb[(size_t)i * r + j], s_vec[1][j], acc);
-      double f = 0.0;
-      for (int e = lane; e < rq.mf; e += 64) f = fma(Ff[(size_t)blockIdx.x * rq.mf + e], rq.Zf[(size_t)e * r + i], f);
-      const double v = rtw::wave_sum(fma(rq.dt, f, acc));
-      if (lane == 0) {
-        s_vec[0][i] = v;
-        rb[i] = v;
-      }
+    double f = 0.0;
+    if (tid < r) {
+      const double* Ff = (rq.ctr ? rq.Ff + *rq.ctr * rq.ff_stride : rq.Ff) + (size_t)blockIdx.x * rq.mf;
+      for (int e = 0; e < rq.mf; ++e) f = fma(Ff[e], rq.Zf[(size_t)e * r + tid], f);
+    }
+    matvec(sT, s_vec[1], s_vec[2]);
+    if (tid < r) {
+      const double v = fma(rq.dt, f, s_vec[2][tid]);
+      s_vec[0][tid] = v;
+      rb[tid] = v;
     }
   } else if (tid < r) {
     s_vec[0][tid] = rb[tid];
@@ -303,48 +369,53 @@ __global__ __launch_bounds__(NS_THREADS) void newton_solve_kernel(const double* 
     atomicAdd(reinterpret_cast<unsigned long long*>(&counters[RT_CNT_NS_RESTART]), (unsigned long long)n_restart);
     atomicAdd(reinterpret_cast<unsigned long long*>(&counters[RT_CNT_SOLVES]), 1ull);
   }
-  if (status != 0) {  // leave rhs for the LU fallback and make the next call start afresh
+  if (status != 0) {
+    // The tracking gave up on this system (singular to working precision, or no contraction even from the safe
+    // start): pivoted LU right here, out of the copy of K this workgroup already holds, and the next call starts
+    // afresh.  (It used to be a second launch per step that found nothing to do in all but a handful of steps.)
     for (int i = wid; i < r; i += NS_THREADS / 64)
       for (int j = lane; j < r; j += 64) Xb[i * r + j] = 0.0;
-    if (info && tid == 0) info[blockIdx.x] = status;
+    if (tid == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[RT_CNT_LU_FALLBACK]), 1ull);
+    int lu_parts = NS_THREADS / r;
+    if (lu_parts > 8) lu_parts = 8;
+    __syncthreads();
+    const int sing = lu_solve_lds<NS_THREADS>(sK, S, s_vec[0], r, lu_parts, rb);
+    if (info && tid == 0) info[blockIdx.x] = sing ? RT_WARN_SINGULAR : 0;
+    if (adv.enabled) {
+      __syncthreads();
+      hsweep_advance_rows(adv, blockIdx.x, r, rhs, 1, s_vec[1], tid, NS_THREADS);
+    }
     return;
   }
   // x = X b, one refinement step against K:  x += X (b - K x)
-  double x = 0.0;
-  if (tid < r) {
-    for (int j = 0; j < r; ++j) x = fma(sX[tid * S + j], s_vec[0][j], x);
-    s_vec[1][tid] = x;
-  }
+  matvec(sX, s_vec[0], s_vec[1]);
+  const double x = (tid < r) ? s_vec[1][tid] : 0.0;
+  matvec(sK, s_vec[1], s_vec[2]);
+  if (tid < r) s_vec[2][tid] = s_vec[0][tid] - s_vec[2][tid];
   __syncthreads();
-  if (tid < r) {
-    double rr = s_vec[0][tid];
-    for (int j = 0; j < r; ++j) rr = fma(-sK[tid * S + j], s_vec[1][j], rr);
-    s_vec[2][tid] = rr;
-  }
-  __syncthreads();
-  if (tid < r) {
-    for (int j = 0; j < r; ++j) x = fma(sX[tid * S + j], s_vec[2][j], x);
-    rb[tid] = x;
-  }
+  matvec(sX, s_vec[2], s_vec[1]);
+  if (tid < r) rb[tid] = x + s_vec[1][tid];
   for (int i = wid; i < r; i += NS_THREADS / 64)
     for (int j = lane; j < r; j += 64) Xb[i * r + j] = sX[i * S + j];
   if (info && tid == 0) info[blockIdx.x] = status;
+  if (adv.enabled) {  // the hyper-reduced sweep's end of step for this system
+    __syncthreads();  // rb is complete and visible in this workgroup
+    hsweep_advance_rows(adv, blockIdx.x, r, rhs, 1, s_vec[1], tid, NS_THREADS);
+  }
 }
 
 }  // namespace
 
-static int dense_solve_launch(rt_ctx* ctx, double* K, double* rhs, int64_t r, int64_t B, int* info, const int* only_if);
+
+static int dense_solve_launch(rt_ctx* ctx, double* K, double* rhs, int64_t r, int64_t B, int* info, const int* only_if,
+                              const rt_advance* advance);
 
 extern "C" int rt_dense_solve_batched(rt_ctx* ctx, double* K, double* rhs, int64_t r, int64_t B, int* info) {
-  return dense_solve_launch(ctx, K, rhs, r, B, info, nullptr);
+  return dense_solve_launch(ctx, K, rhs, r, B, info, nullptr, nullptr);
 }
 
-// Internal (sweep.hip): the LU solve for the systems b with only_if[b] != 0 (a device array, no host sync).
-int rt_dense_solve_batched_if(rt_ctx* ctx, double* K, double* rhs, int64_t r, int64_t B, int* info, const int* only_if) {
-  return dense_solve_launch(ctx, K, rhs, r, B, info, only_if);
-}
-
-static int dense_solve_launch(rt_ctx* ctx, double* K, double* rhs, int64_t r, int64_t B, int* info, const int* only_if) {
+static int dense_solve_launch(rt_ctx* ctx, double* K, double* rhs, int64_t r, int64_t B, int* info, const int* only_if,
+                              const rt_advance* advance) {
   if (!ctx) return RT_ERR_ARG;
   RT_ARG_CHECK(ctx, K && rhs && r >= 1 && B >= 1);
   if (r > 128) {
@@ -357,7 +428,7 @@ static int dense_solve_launch(rt_ctx* ctx, double* K, double* rhs, int64_t r, in
   int parts = SOLVE_THREADS / (int)r;  // threads per row
   if (parts > 8) parts = 8;
   hipLaunchKernelGGL(dense_solve_kernel, dim3((unsigned)B), dim3(SOLVE_THREADS), lds, ctx->stream, K, rhs, (int)r,
-                     parts, info, only_if, ctx->dev_counters);
+                     parts, info, only_if, ctx->dev_counters, advance ? *advance : rt_advance{});
   RT_HIP_CHECK(ctx, hipGetLastError());
   return RT_OK;
 }
@@ -367,7 +438,7 @@ static int dense_solve_launch(rt_ctx* ctx, double* K, double* rhs, int64_t r, in
 // do not fit the LDS (r > 80): the caller uses rt_dense_solve_batched.  With `recipe` the kernel forms the
 // right-hand side itself (and leaves it in rhs) instead of reading it.
 int rt_newton_solve_batched(rt_ctx* ctx, const double* K, double* Xinv, double* rhs, int64_t r, int64_t B,
-                            int have_prev, int* info, const rt_newton_rhs* recipe) {
+                            int have_prev, int* info, const rt_newton_rhs* recipe, const rt_advance* advance) {
   const int rp = (int)((r + 15) / 16) * 16;
   int S = rp;
   while (S % 4 != 2) ++S;  // 2 S == 4 (mod 8): the 16 rows of an A-operand read fall in distinct LDS banks
@@ -377,7 +448,14 @@ int rt_newton_solve_batched(rt_ctx* ctx, const double* K, double* Xinv, double* 
   rt_newton_rhs rq{};
   if (recipe) rq = *recipe;
   hipLaunchKernelGGL(newton_solve_kernel, dim3((unsigned)B), dim3(NS_THREADS), lds, ctx->stream, K, Xinv, rhs, (int)r, S,
-                     have_prev, info, rq, ctx->dev_counters);
+                     have_prev, info, rq, ctx->dev_counters, advance ? *advance : rt_advance{});
   RT_HIP_CHECK(ctx, hipGetLastError());
   return RT_OK;
+}
+
+extern "C" int rt_tracked_solve_batched(rt_ctx* ctx, const double* K, double* Xinv, double* rhs, int64_t r, int64_t B,
+                                        int have_prev, int* info) {
+  if (!ctx) return RT_ERR_ARG;
+  RT_ARG_CHECK(ctx, K && Xinv && rhs && r >= 1 && B >= 1);
+  return rt_newton_solve_batched(ctx, K, Xinv, rhs, r, B, have_prev ? 1 : 0, info, nullptr, nullptr);
 }

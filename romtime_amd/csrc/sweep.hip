@@ -10,6 +10,7 @@
 // The operators are affine in precomputed value vectors on one CSR pattern (the form MDEIM itself
 // produces, and what a closed-form 1-D assembly yields); the state-dependent term is diag(u*) T.
 #include "common.h"
+#include "sweep_advance.h"
 
 namespace {
 
@@ -73,60 +74,9 @@ __global__ void sweep_store_kernel(const double* __restrict__ x, double* __restr
 // and G[B + b] = [ F_mass | 0 | 0 ], so that ONE skinny GEMM with Z yields K_N (rows 0..B-1) and M_N (rows B..2B-1)
 // Optionally first closes a step (x -> u^n, u^n -> u^{n-1}, trajectory), then builds the coefficient rows of the
 // next one from the updated state: one launch between two steps instead of two.
-__global__ void hsweep_advance_kernel(const double* __restrict__ x, double* __restrict__ un,
-                                      double* __restrict__ unm1, double* __restrict__ out, long step_done, long nt,
-                                      int keep_prev, int do_store, int do_coef, const double* Fm,
-                                      const double* Fl, const double* __restrict__ W,
-                                      const double* Cn, const double* Sn, int extrapolate,
-                                      int mm, int ml, int mn, int r, double bdf, double dt, double* __restrict__ G,
-                                      const long* __restrict__ ctr) {
+__global__ void hsweep_advance_kernel(const double* __restrict__ x, int do_store, int r, const rt_advance a) {
   extern __shared__ double su[];  // u* of the coming step
-  const int b = blockIdx.x, t = threadIdx.x, M = mm + ml + mn;
-  if (ctr) {
-    // graph replay: the step comes from the device counter; Fm / Fl / Cn / Sn are the table bases, bdf is that of
-    // every step after the first
-    step_done = *ctr;
-    const long next = step_done + 1;
-    do_coef = next < nt;
-    const long s2 = do_coef ? next : 0;
-    Fm += s2 * gridDim.x * mm;
-    if (Fl) Fl += s2 * gridDim.x * ml;
-    if (Cn) Cn += s2 * gridDim.x * mn;
-    if (Sn) Sn += s2 * gridDim.x;
-  }
-  for (int j = t; j < r; j += blockDim.x) {
-    double u = un[(long)b * r + j], up = unm1[(long)b * r + j];
-    if (do_store) {
-      const double v = x[(long)b * r + j];
-      if (keep_prev) {
-        unm1[(long)b * r + j] = u;
-        up = u;
-      }
-      un[(long)b * r + j] = v;
-      out[((long)b * nt + step_done) * r + j] = v;
-      u = v;
-    }
-    su[j] = extrapolate ? 2.0 * u - up : u;
-  }
-  if (!do_coef) return;
-  __syncthreads();
-  const double sc = Sn ? Sn[b] : 1.0;
-  for (int e = t; e < M; e += blockDim.x) {
-    double g;
-    if (e < mm) {
-      g = bdf * Fm[(long)b * mm + e];
-    } else if (e < mm + ml) {
-      g = dt * Fl[(long)b * ml + (e - mm)];
-    } else {
-      const int q = e - mm - ml;
-      double acc = Cn ? Cn[(long)b * mn + q] : 0.0;
-      const double* w = W + (long)q * r;
-      for (int j = 0; j < r; ++j) acc = fma(w[j], su[j], acc);
-      g = dt * sc * acc;
-    }
-    G[(long)b * M + e] = g;
-    G[(long)(gridDim.x + b) * M + e] = (e < mm) ? Fm[(long)b * mm + e] : 0.0;
-  }
+  hsweep_advance_rows(a, blockIdx.x, r, x, do_store, su, threadIdx.x, blockDim.x);
 }
 
 __global__ void hsweep_count_kernel(long* ctr) { *ctr += 1; }
@@ -224,11 +174,9 @@ extern "C" int rt_rom_bdf_sweep(rt_ctx* ctx, const rt_sweep_desc* d, double* uN_
                        d->dt, F ? d->rhs_coef + step * B * F : nullptr, fN, F, (int)r, rhs);
     RT_HIP_CHECK(ctx, hipGetLastError());
     // consecutive K_N differ by O(dt): refresh the tracked inverse on the matrix cores; LU only for the systems
-    // where that fails (decided on the device) or when r is too large for the LDS-resident iteration
+    // where that fails (inside the same kernel) or when r is too large for the LDS-resident iteration
     rc = rt_newton_solve_batched(ctx, KN, Xinv, rhs, r, B, step > 0 ? 1 : 0, info);
-    if (rc == RT_OK)
-      rc = rt_dense_solve_batched_if(ctx, KN, rhs, r, B, info, info);
-    else if (rc == RT_ERR_UNSUPPORTED)
+    if (rc == RT_ERR_UNSUPPORTED)
       rc = rt_dense_solve_batched(ctx, KN, rhs, r, B, info);
     if (rc != RT_OK) return rc;
     hipLaunchKernelGGL(sweep_store_kernel, dim3((unsigned)B), dim3(128), 0, st, rhs, un, unm1, uN_out, step, nt, (int)r,
@@ -281,24 +229,31 @@ extern "C" int rt_hrom_bdf_sweep(rt_ctx* ctx, const rt_hsweep_desc* d, double* u
   RT_HIP_CHECK(ctx, hipMemsetAsync(unm1, 0, sizeof(double) * B * r, st));
   RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->dev_counters + RT_CNT_NS_ITER, 0, sizeof(long) * 4, st));  // rt_last_sweep_stats
 
-  auto advance = [&](long next, int do_store) {  // close step next-1 (if any) and prepare the rows of step `next`
+  // the end-of-step work for closing step next-1 (if any) and preparing the rows of step `next`
+  auto advance_args = [&](long next) {
     const bool has_next = next < nt;
     const long s2 = has_next ? next : 0;
-    hipLaunchKernelGGL(hsweep_advance_kernel, dim3((unsigned)B), dim3(256), sizeof(double) * r, st, rhs, un, unm1, uN_out,
-                       next - 1, nt, d->bdf2 ? 1 : 0, do_store, has_next ? 1 : 0, d->F_mass + s2 * B * mm,
-                       ml ? d->F_lin + s2 * B * ml : nullptr, d->W, d->C_nl ? d->C_nl + s2 * B * mn : nullptr,
-                       d->S_nl ? d->S_nl + s2 * B : nullptr, d->bdf2 ? 1 : 0, (int)mm, (int)ml, (int)mn, (int)r,
-                       (d->bdf2 && next > 0) ? 1.5 : 1.0, d->dt, G, (const long*)nullptr);
+    rt_advance a{};
+    a.un = un; a.unm1 = unm1; a.out = uN_out; a.step_done = next - 1; a.nt = nt;
+    a.keep_prev = d->bdf2 ? 1 : 0; a.do_coef = has_next ? 1 : 0;
+    a.Fm = d->F_mass + s2 * B * mm; a.Fl = ml ? d->F_lin + s2 * B * ml : nullptr; a.W = d->W;
+    a.Cn = d->C_nl ? d->C_nl + s2 * B * mn : nullptr; a.Sn = d->S_nl ? d->S_nl + s2 * B : nullptr;
+    a.extrapolate = d->bdf2 ? 1 : 0; a.mm = (int)mm; a.ml = (int)ml; a.mn = (int)mn;
+    a.bdf = (d->bdf2 && next > 0) ? 1.5 : 1.0; a.dt = d->dt; a.G = G; a.ctr = nullptr; a.B = (int)B; a.enabled = 1;
+    return a;
+  };
+  auto advance = [&](long next, int do_store) {
+    hipLaunchKernelGGL(hsweep_advance_kernel, dim3((unsigned)B), dim3(256), sizeof(double) * r, st, rhs, do_store, (int)r,
+                       advance_args(next));
   };
   advance(0, 0);
   RT_HIP_CHECK(ctx, hipGetLastError());
   const double c0 = d->bdf2 ? 2.0 : 1.0, c1 = d->bdf2 ? -0.5 : 0.0;
-  // Steps 1 .. nt-1 are the same four launches with only table offsets moving.  With rt_ctx_set_option(ctx,
-  // "sweep_graph", 1) they are captured ONCE as a hipGraph whose kernels take the step from a device counter, and
-  // replayed; step 0 runs eagerly (first BDF step, inverse tracking starts, scratch arenas get their sizes).  It is
-  // an option, not the default: on the pool's boxes the host stays ahead of the device with plain launches (92 us
-  // per step, 85 us of them kernels) and the replay is slower (97 us: the graph's own inter-node gaps and the
-  // counter kernel); it pays where the host is what limits the rate (110 us per step was measured on one box).
+  // Steps 1 .. nt-1 are the same two launches (expansion GEMM, tracked solve with the end of the step in its tail) with
+  // only table offsets moving.  With rt_ctx_set_option(ctx, "sweep_graph", 1) they are captured ONCE as a hipGraph whose
+  // kernels take the step from a device counter, and replayed; step 0 runs eagerly (first BDF step, inverse tracking
+  // starts, scratch arenas get their sizes).  It is an option, not the default: on the pool's boxes plain launches
+  // are faster (60 us per step against 69-86 us replayed: the graph's own inter-node gaps and the counter kernel).
   // Not with r > 80 (no inverse tracking) or in profile mode (event pairs inside the GEMM).
   const bool use_graph = ctx->sweep_graph && nt > 2 && r <= 80 && !ctx->profile;
   for (long step = 0; step < nt; ++step) {
@@ -322,12 +277,10 @@ extern "C" int rt_hrom_bdf_sweep(rt_ctx* ctx, const rt_hsweep_desc* d, double* u
       RT_HIP_CHECK(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
       rc = rt_gemm_strided(ctx, G, 1, M, d->Z, rr, 1, M, 2 * B, rr, KN, rr, 1, false, false);
       rt_newton_rhs rq{MN, un, unm1, c0, c1, d->dt, mf ? d->F_rhs : nullptr, d->Zf, (int)mf, ctr, B * mf};
-      if (rc == RT_OK) rc = rt_newton_solve_batched(ctx, KN, Xinv, rhs, r, B, 1, info, &rq);
-      if (rc == RT_OK) rc = rt_dense_solve_batched_if(ctx, KN, rhs, r, B, info, info);
-      hipLaunchKernelGGL(hsweep_advance_kernel, dim3((unsigned)B), dim3(256), sizeof(double) * r, st, rhs, un, unm1, uN_out,
-                         0L, nt, d->bdf2 ? 1 : 0, 1, 1, d->F_mass, ml ? d->F_lin : nullptr, d->W, d->C_nl, d->S_nl,
-                         d->bdf2 ? 1 : 0, (int)mm, (int)ml, (int)mn, (int)r, d->bdf2 ? 1.5 : 1.0, d->dt, G,
-                         (const long*)ctr);
+      rt_advance ga = advance_args(1);   // table bases + device counter: the replayed launches cannot carry the step
+      ga.Fm = d->F_mass; ga.Fl = ml ? d->F_lin : nullptr; ga.Cn = d->C_nl; ga.Sn = d->S_nl;
+      ga.bdf = d->bdf2 ? 1.5 : 1.0; ga.do_coef = 1; ga.ctr = ctr;
+      if (rc == RT_OK) rc = rt_newton_solve_batched(ctx, KN, Xinv, rhs, r, B, 1, info, &rq, &ga);
       hipLaunchKernelGGL(hsweep_count_kernel, dim3(1), dim3(1), 0, st, ctr);
       const hipError_t cap = hipStreamEndCapture(st, &graph);
       if (rc != RT_OK || cap != hipSuccess || graph == nullptr) {
@@ -355,9 +308,13 @@ extern "C" int rt_hrom_bdf_sweep(rt_ctx* ctx, const rt_hsweep_desc* d, double* u
     rc = rt_gemm_strided(ctx, G, 1, M, d->Z, rr, 1, M, 2 * B, rr, KN, rr, 1, false, false);
     if (rc != RT_OK) return rc;
     rt_newton_rhs rq{MN, un, unm1, c0, c1, d->dt, mf ? d->F_rhs + step * B * mf : nullptr, d->Zf, (int)mf};
-    rc = rt_newton_solve_batched(ctx, KN, Xinv, rhs, r, B, step > 0 ? 1 : 0, info, &rq);
+    // two launches per step: the expansion GEMM and the solve, which forms the right-hand side, falls back to a
+    // pivoted LU by itself where the tracked inverse fails, and closes the step (state, trajectory, next rows of G)
+    const rt_advance adv = advance_args(step + 1);
+    rc = rt_newton_solve_batched(ctx, KN, Xinv, rhs, r, B, step > 0 ? 1 : 0, info, &rq, &adv);
     if (rc == RT_OK) {
-      rc = rt_dense_solve_batched_if(ctx, KN, rhs, r, B, info, info);
+      RT_HIP_CHECK(ctx, hipGetLastError());
+      continue;
     } else if (rc == RT_ERR_UNSUPPORTED) {  // r > 80: right-hand side by its own kernel, then the LU
       hipLaunchKernelGGL(hsweep_rhs_kernel, dim3((unsigned)B), dim3(128), sizeof(double) * r, st, MN, un, unm1, c0, c1,
                          d->dt, mf ? d->F_rhs + step * B * mf : nullptr, d->Zf, (int)mf, (int)r, rhs);

@@ -18,7 +18,6 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 namespace {
 
 constexpr int TS_THREADS = 256;
-constexpr int TS_BM = 64;      // rows per workgroup
 constexpr int TS_KS = 32;      // contraction columns per stage
 constexpr int TS_SA = 34;      // LDS stride of the X stage ([row][k]): 2 SA == 4 (mod 8) -> the 16 rows of an
                                // A-operand read fall in distinct banks

@@ -242,6 +242,22 @@ def dense_solve(K: torch.Tensor, b: torch.Tensor):
     return (bw[0] if single else bw), info
 
 
+def tracked_solve(K: torch.Tensor, b: torch.Tensor, Xinv: torch.Tensor = None):
+    """Solve K x = b for a batch ([B,r,r], [B,r]) with the inverse tracked in ``Xinv`` ([B,r,r], carried from call to
+    call; None = first call).  Returns (x, info, Xinv).  rt_tracked_solve_batched (r <= 80)."""
+    ctx = Context.current()
+    Kw = K.reshape(-1, K.shape[-2], K.shape[-1]).contiguous()
+    bw = b.reshape(Kw.shape[0], -1).contiguous().clone()
+    B, r, _ = Kw.shape
+    have_prev = Xinv is not None
+    if Xinv is None:
+        Xinv = torch.zeros_like(Kw)
+    info = torch.zeros(B, dtype=torch.int32, device=K.device)
+    ctx.check(ctx.lib.rt_tracked_solve_batched(ctx.handle, _ptr(Kw), _ptr(Xinv), _ptr(bw), r, B, int(have_prev), _ptr(info)),
+              "rt_tracked_solve_batched")
+    return bw, info, Xinv
+
+
 P1_KINDS = dict(mass=0, stiffness=1, convection=2, trilinear=3, load=4)
 
 

@@ -190,6 +190,57 @@ def test_dense_solve_singular_flag(ops):
     assert int(info[0].item()) == 2
 
 
+@pytest.mark.parametrize("r", [5, 40, 80])
+def test_tracked_solve_follows_a_moving_matrix(ops, r):
+    """rt_tracked_solve_batched: first call from the safe start, then three steps of a slowly moving K from the carried
+    inverse; every answer against np.linalg.solve (what rom.py:492's GMRES converges to)."""
+    from romtime_amd._lib import Context
+
+    rng = np.random.RandomState(r)
+    B = 6
+    K0 = rng.standard_normal((B, r, r)) / np.sqrt(r) + 2.0 * np.eye(r)
+    dK = rng.standard_normal((B, r, r)) / np.sqrt(r)
+    ctx = Context.current()
+    before = ctx.sweep_stats()
+    Xinv = None
+    for step in range(4):
+        K = K0 + 1e-3 * step * dK
+        b = rng.standard_normal((B, r))
+        x, info, Xinv = ops.tracked_solve(ops.to_device(K), ops.to_device(b), Xinv)
+        ref = np.linalg.solve(K, b[..., None])[..., 0]
+        np.testing.assert_allclose(x.cpu().numpy(), ref, rtol=1e-10, atol=1e-12)
+        assert int(info.abs().sum().item()) == 0
+    after = ctx.sweep_stats()
+    assert after["lu_fallbacks"] == before["lu_fallbacks"]
+    assert after["solves"] - before["solves"] == 4 * B
+
+
+def test_tracked_solve_falls_back_to_lu_in_the_same_kernel(ops):
+    """A matrix the Newton-Schulz iteration cannot invert in its iteration budget (condition number 1e17, diagonal so
+    that the exact answer is known), one it can, and an exactly singular one: the first is solved by the pivoted LU
+    inside the kernel (counter), the last is flagged."""
+    from romtime_amd._lib import Context
+
+    r = 12
+    rng = np.random.RandomState(0)
+    K = np.zeros((3, r, r))
+    d_bad = np.ones(r)
+    d_bad[-1] = 1e-17
+    K[0] = np.diag(d_bad)[::-1]                    # a row permutation of the diagonal: the LU has to pivot
+    K[1] = rng.standard_normal((r, r)) + 3.0 * np.eye(r)
+    K[2] = np.ones((r, r))                         # rank one
+    b = rng.standard_normal((3, r))
+    ctx = Context.current()
+    before = ctx.sweep_stats()
+    x, info, _ = ops.tracked_solve(ops.to_device(K), ops.to_device(b))
+    after = ctx.sweep_stats()
+    x = x.cpu().numpy()
+    np.testing.assert_allclose(x[0], (b[0] / d_bad[::-1])[::-1], rtol=1e-14)
+    np.testing.assert_allclose(x[1], np.linalg.solve(K[1], b[1]), rtol=1e-10, atol=1e-12)
+    assert info.cpu().tolist()[:2] == [0, 0] and int(info[2].item()) == 2
+    assert after["lu_fallbacks"] - before["lu_fallbacks"] == 2
+
+
 def test_unsupported_sizes_fail_loudly(ops):
     from romtime_amd._lib import RomtimeHipError
 
