@@ -111,6 +111,7 @@ struct rt_newton_rhs {  // b = M_N (c0 u^n + c1 u^{n-1}) + dt Zf^T F_rhs, per sy
   const double* Ff;    // B x mf
   const double* Zf;    // mf x r
   int mf;
+  long mn_stride = -1;        // doubles between the M_N of consecutive systems (-1: r * r; 0: one M_N for all)
   const long* ctr = nullptr;  // device step counter: Ff is the table base and the step's rows start at *ctr * ff_stride
   long ff_stride = 0;         // (graph replay of a sweep: the launch parameters cannot carry the step)
 };
@@ -124,6 +125,9 @@ int rt_newton_solve_batched(rt_ctx* ctx, const double* K, double* Xinv, double* 
 // nullptr to have it built on every call.
 size_t rt_project_stage_table_bytes(int64_t N);
 int rt_project_stage_table(rt_ctx* ctx, const int64_t* indptr, const int64_t* indices, int64_t N, void* table);
+// `banded`: 1 / 0 when the caller has read the table's header (rt_project_stage_table_banded) and only the kernel
+// variant for that kind of pattern need be launched; -1: both are launched and the wrong one returns at once.
 int rt_project_fused(rt_ctx* ctx, const int64_t* indptr, const int64_t* indices, const double* data, int64_t d_es,
                      int64_t d_bs, int64_t B, int64_t N, const double* V, int64_t ldv, int64_t r, double* AN,
-                     const void* stage_table = nullptr);
+                     const void* stage_table = nullptr, int banded = -1);
+int rt_project_stage_table_banded(rt_ctx* ctx, const void* table, int* banded);   // synchronises the ctx stream

@@ -467,6 +467,14 @@ __global__ void project_reduce_kernel(const double* __restrict__ slab, int S, lo
 
 size_t rt_project_stage_table_bytes(int64_t N) { return TABLE_HEADER + sizeof(StageRec) * (size_t)((N + PK - 1) / PK); }
 
+int rt_project_stage_table_banded(rt_ctx* ctx, const void* table, int* banded) {
+  int any = 0;
+  RT_HIP_CHECK(ctx, hipMemcpyAsync(&any, table, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+  RT_HIP_CHECK(ctx, hipStreamSynchronize(ctx->stream));
+  *banded = any ? 0 : 1;
+  return RT_OK;
+}
+
 int rt_project_stage_table(rt_ctx* ctx, const int64_t* indptr, const int64_t* indices, int64_t N, void* table) {
   const long stages = (N + PK - 1) / PK;
   RT_HIP_CHECK(ctx, hipMemsetAsync(table, 0, TABLE_HEADER, ctx->stream));
@@ -511,9 +519,11 @@ static int fused_blocks_per_cu(rt_ctx* ctx, int tr, int* out) {
 }
 
 template <int TR>
-static int launch_fused(rt_ctx* ctx, const ProjParams& p, unsigned grid) {
-  hipLaunchKernelGGL((project_fused_kernel<TR, false>), dim3(grid), dim3(PT), fused_lds<TR>(), ctx->stream, p, p.rec, p.any_unwindowed);
-  hipLaunchKernelGGL((project_fused_kernel<TR, true>), dim3(grid), dim3(PT), fused_lds<TR>(), ctx->stream, p, p.rec, p.any_unwindowed);
+static int launch_fused(rt_ctx* ctx, const ProjParams& p, unsigned grid, int banded) {
+  if (banded != 0)
+    hipLaunchKernelGGL((project_fused_kernel<TR, false>), dim3(grid), dim3(PT), fused_lds<TR>(), ctx->stream, p, p.rec, p.any_unwindowed);
+  if (banded != 1)
+    hipLaunchKernelGGL((project_fused_kernel<TR, true>), dim3(grid), dim3(PT), fused_lds<TR>(), ctx->stream, p, p.rec, p.any_unwindowed);
   RT_HIP_CHECK(ctx, hipGetLastError());
   return RT_OK;
 }
@@ -522,7 +532,7 @@ static int launch_fused(rt_ctx* ctx, const ProjParams& p, unsigned grid) {
 // rt_project_stage_table for this pattern, or nullptr (built here, one small launch).
 int rt_project_fused(rt_ctx* ctx, const int64_t* indptr, const int64_t* indices, const double* data, int64_t d_es,
                      int64_t d_bs, int64_t B, int64_t N, const double* V, int64_t ldv, int64_t r, double* AN,
-                     const void* stage_table) {
+                     const void* stage_table, int banded) {
   if (r > RMAX) return RT_ERR_UNSUPPORTED;
   if (((int64_t)WROWS * ldv + RMAX) * 8 >= (1LL << 31) || d_es * 8 * EMAX >= (1LL << 31) || N >= (1LL << 31) - 2 * PK ||
       N * ldv * 8 >= (1LL << 32))
@@ -586,14 +596,14 @@ int rt_project_fused(rt_ctx* ctx, const int64_t* indptr, const int64_t* indices,
   }
   const unsigned grid = (unsigned)(B * S);
   switch (tr) {
-    case 1: rc = launch_fused<1>(ctx, p, grid); break;
-    case 2: rc = launch_fused<2>(ctx, p, grid); break;
-    case 3: rc = launch_fused<3>(ctx, p, grid); break;
-    case 4: rc = launch_fused<4>(ctx, p, grid); break;
-    case 5: rc = launch_fused<5>(ctx, p, grid); break;
-    case 6: rc = launch_fused<6>(ctx, p, grid); break;
-    case 7: rc = launch_fused<7>(ctx, p, grid); break;
-    default: rc = launch_fused<8>(ctx, p, grid); break;
+    case 1: rc = launch_fused<1>(ctx, p, grid, banded); break;
+    case 2: rc = launch_fused<2>(ctx, p, grid, banded); break;
+    case 3: rc = launch_fused<3>(ctx, p, grid, banded); break;
+    case 4: rc = launch_fused<4>(ctx, p, grid, banded); break;
+    case 5: rc = launch_fused<5>(ctx, p, grid, banded); break;
+    case 6: rc = launch_fused<6>(ctx, p, grid, banded); break;
+    case 7: rc = launch_fused<7>(ctx, p, grid, banded); break;
+    default: rc = launch_fused<8>(ctx, p, grid, banded); break;
   }
   if (rc != RT_OK) return rc;
   if (ctx->profile) {

@@ -219,7 +219,7 @@ __global__ __launch_bounds__(NS_THREADS) void newton_solve_kernel(const double* 
 
   // K, the carried inverse and (when the right-hand side is formed here) M_N come in together: one round of global
   // loads, M_N parked in sT until the first product needs the space
-  const double* Mb = rq.MN ? rq.MN + (size_t)blockIdx.x * r * r : nullptr;
+  const double* Mb = rq.MN ? rq.MN + (size_t)blockIdx.x * (rq.mn_stride < 0 ? (long)r * r : rq.mn_stride) : nullptr;
   {
     // rp <= 80: a wave has at most 10 rows (i = wid + 8 q) of at most 2 x 64 columns.  Fixed trip counts, loads of
     // half the rows issued before any LDS store: a loop over runtime bounds went load - wait - store twenty times

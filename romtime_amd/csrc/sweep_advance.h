@@ -20,6 +20,7 @@ struct rt_advance {
   double* G;             // 2 B x (mm + ml + mn) coefficient rows of the next step
   const long* ctr;       // graph replay: device step counter (or nullptr)
   int B;
+  double* xT;            // r x B: the new u^n transposed as well (direct sweep: operand of the lift), or nullptr
   int enabled;           // 0: the solver kernels leave the step alone
 };
 
@@ -49,6 +50,7 @@ __device__ __forceinline__ void hsweep_advance_rows(rt_advance a, int b, int r, 
         up = u;
       }
       a.un[(long)b * r + j] = v;
+      if (a.xT) a.xT[(long)j * a.B + b] = v;
       a.out[((long)b * a.nt + a.step_done) * r + j] = v;
       u = v;
     }
