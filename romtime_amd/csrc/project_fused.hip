@@ -22,6 +22,7 @@
 // stage s+1 independent of any other load (they are all in flight while stage s computes).
 #include "common.h"
 
+#include <cmath>
 #include <cstdlib>
 #include <type_traits>
 
@@ -557,18 +558,24 @@ int rt_project_fused(rt_ctx* ctx, const int64_t* indptr, const int64_t* indices,
   if (rc0 != RT_OK) return rc0;
   const long resident = (long)per_cu * ctx->num_cus;
   const long stages = (N + PK - 1) / PK;
-  long s_hi = (2 * resident + B - 1) / B;
+  // one to four rounds of resident workgroups: the fullest last round wins (120 vectors: 17 ranges = 3.98 rounds run
+  // at 0.66 of the peak, 8 ranges = 1.9 rounds at 0.62), ties go to the count closest to two rounds (32 vectors:
+  // 16, 32, 48 and 64 ranges all fill their rounds; 32 measured best)
+  long s_hi = (4 * resident + B - 1) / B;
   if (s_hi > stages / 8) s_hi = stages / 8;   // at least 8 stages per workgroup
   if (s_hi < 1) s_hi = 1;
-  const long s_lo = s_hi / 2 > 1 ? s_hi / 2 : 1;
+  long s_lo = resident / B;
+  if (s_lo < 1) s_lo = 1;
+  if (s_lo > s_hi) s_lo = s_hi;
   long S = s_hi, kps = 0;
-  double best = -1.0;
+  double best = -1.0, best_off = 1e30;
   for (long cand = s_lo; cand <= s_hi; ++cand) {
     const long per = ((N + cand - 1) / cand + PK - 1) / PK * PK;
     const long s_eff = (N + per - 1) / per;
     const long g = B * s_eff, rounds = (g + resident - 1) / resident;
     const double fill = (double)g / (double)(rounds * resident);
-    if (fill >= best) { best = fill; S = s_eff; kps = per; }   // ties: more, smaller ranges
+    const double off = fabs((double)g / (double)resident - 2.0);
+    if (fill > best + 1e-9 || (fill > best - 1e-9 && off < best_off)) { best = fill; best_off = off; S = s_eff; kps = per; }
   }
   p.k_per_split = (int)kps;
   p.S = (int)S;
