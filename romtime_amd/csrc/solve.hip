@@ -16,6 +16,7 @@
 #include "common.h"
 #include "wave_ops.h"
 #include "sweep_advance.h"
+#include "tile_layout.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(NS_THREADS) void newton_solve_kernel(const double* 
                                                                   const rt_newton_rhs rq, long* counters,
                                                                   const rt_advance adv) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int tr = (r + 15) / 16, rp = tr * 16, ntile = tr * tr;
+  const int tr = (r + 15) / 16, rp = tr * 16;
   double* sK = sm;                    // [rp][S], padded with the identity
   double* sX = sK + (size_t)rp * S;   // [rp][S]
   double* sT = sX + (size_t)rp * S;   // [rp][S]
@@ -273,24 +274,37 @@ __global__ __launch_bounds__(NS_THREADS) void newton_solve_kernel(const double* 
   }
   __syncthreads();
 
-  // C(ti, tj) = sum_k A[16 ti + i][k] B[k][16 tj + j]; tile t = wid + 8 q belongs to this wave (q < 4 as r <= 80)
-  constexpr int NSQ = 4;
-  auto tiles_product = [&](const double* A, const double* Bm, d4 (&acc)[NSQ]) {
-    const double* a[NSQ];
-    const double* bq[NSQ];
+  // C(ti, tj) = sum_k A[16 ti + i][k] B[k][16 tj + j] on the matrix cores, operands out of LDS.  A wave owns one
+  // rectangular block of tiles (tile_layout.h; at most 2 x 3 for r <= 80), so a k-step costs ni + nj LDS reads for
+  // ni nj MFMAs (scattered tiles t = wid + 8 q read two operands per MFMA and took 9 us per 80^3 product).
+  constexpr int NBI = 2, NBJ = 3;
+  const Blk bk = tile_block(tr, wid);
+  auto tiles_product = [&](const double* A, const double* Bm, d4 (&acc)[NBI][NBJ]) {
+    const double* ap[NBI];
+    const double* bp[NBJ];
 #pragma unroll
-    for (int q = 0; q < NSQ; ++q) {
-      const int t = (wid + 8 * q < ntile) ? wid + 8 * q : 0;
-      const int ti = t / tr, tj = t - ti * tr;
-      a[q] = A + (16 * ti + l15) * S + l4;
-      bq[q] = Bm + l4 * S + 16 * tj + l15;
-      acc[q] = d4{0.0, 0.0, 0.0, 0.0};
-    }
-    for (int k4 = 0; k4 < rp / 4; ++k4) {
+    for (int i = 0; i < NBI; ++i) ap[i] = A + (16 * (bk.i0 + (i < bk.ni ? i : 0)) + l15) * S + l4;
 #pragma unroll
-      for (int q = 0; q < NSQ; ++q)
-        if (wid + 8 * q < ntile)  // wave-uniform
-          acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q][4 * k4], bq[q][4 * k4 * S], acc[q], 0, 0, 0);
+    for (int j = 0; j < NBJ; ++j) bp[j] = Bm + l4 * S + 16 * (bk.j0 + (j < bk.nj ? j : 0)) + l15;
+#pragma unroll
+    for (int i = 0; i < NBI; ++i)
+#pragma unroll
+      for (int j = 0; j < NBJ; ++j) acc[i][j] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int k16 = 0; k16 < rp / 16; ++k16)   // rp is a multiple of 16: four k-steps per trip, unrolled
+#pragma unroll
+    for (int ku = 0; ku < 4; ++ku) {
+      const int k4 = 4 * k16 + ku;
+      double a[NBI], bq[NBJ];
+#pragma unroll
+      for (int i = 0; i < NBI; ++i) a[i] = ap[i][4 * k4];
+#pragma unroll
+      for (int j = 0; j < NBJ; ++j) bq[j] = bp[j][4 * k4 * S];
+#pragma unroll
+      for (int i = 0; i < NBI; ++i)
+#pragma unroll
+        for (int j = 0; j < NBJ; ++j)
+          if (i < bk.ni && j < bk.nj)  // wave-uniform
+            acc[i][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[i], bq[j], acc[i][j], 0, 0, 0);
     }
   };
 
@@ -318,22 +332,21 @@ __global__ __launch_bounds__(NS_THREADS) void newton_solve_kernel(const double* 
     ++n_iter;
     // T = K X and the residual ||I - T||_F
     double part = 0.0;
-    d4 acc[NSQ];
+    d4 acc[NBI][NBJ];
     tiles_product(sK, sX, acc);
 #pragma unroll
-    for (int q = 0; q < NSQ; ++q) {
-      const int t = wid + 8 * q;
-      if (t < ntile) {
-        const int ti = t / tr, tj = t - ti * tr;
+    for (int i = 0; i < NBI; ++i)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int row = 16 * ti + l4 + 4 * c, col = 16 * tj + l15;
-          sT[row * S + col] = acc[q][c];
-          const double e = ((row == col) ? 1.0 : 0.0) - acc[q][c];
-          part = fma(e, e, part);
+      for (int j = 0; j < NBJ; ++j)
+        if (i < bk.ni && j < bk.nj) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int row = 16 * (bk.i0 + i) + l4 + 4 * c, col = 16 * (bk.j0 + j) + l15;
+            sT[row * S + col] = acc[i][j][c];
+            const double e = ((row == col) ? 1.0 : 0.0) - acc[i][j][c];
+            part = fma(e, e, part);
+          }
         }
-      }
-    }
     const double res = sqrt(ns_block_sum(part, s_red, tid));  // barriers inside: sT complete
     if (res != res) break;  // NaN: singular to working precision (or bad input)
     if (!restarted && !(res < 0.7)) {  // the carried inverse is no contraction for this K: safe start instead
@@ -346,17 +359,16 @@ __global__ __launch_bounds__(NS_THREADS) void newton_solve_kernel(const double* 
     tiles_product(sX, sT, acc);
     __syncthreads();  // every wave has finished reading the old X
 #pragma unroll
-    for (int q = 0; q < NSQ; ++q) {
-      const int t = wid + 8 * q;
-      if (t < ntile) {
-        const int ti = t / tr, tj = t - ti * tr;
+    for (int i = 0; i < NBI; ++i)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int row = 16 * ti + l4 + 4 * c, col = 16 * tj + l15;
-          sX[row * S + col] = 2.0 * sX[row * S + col] - acc[q][c];
+      for (int j = 0; j < NBJ; ++j)
+        if (i < bk.ni && j < bk.nj) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int row = 16 * (bk.i0 + i) + l4 + 4 * c, col = 16 * (bk.j0 + j) + l15;
+            sX[row * S + col] = 2.0 * sX[row * S + col] - acc[i][j][c];
+          }
         }
-      }
-    }
     __syncthreads();
     if (res < 1e-6) {
       status = 0;

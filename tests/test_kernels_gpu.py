@@ -153,6 +153,53 @@ def test_project_csr(ops, N, r):
     assert _rel(AN, oracle.project_csr(A, V)) < 1e-13
 
 
+@pytest.mark.parametrize("r", [7, 40, 72, 80, 120])
+@pytest.mark.parametrize("pattern", ["ragged_band", "wide", "mixed", "empty_rows"])
+def test_project_fused_pattern_variants(ops, pattern, r):
+    """The code paths of the fused projection the banded test matrices do not reach: rows of unequal length inside a
+    window (predicated gather), patterns no stage of which can be windowed and patterns where a few can not (the
+    kernel's `mixed` variant, gathers out of global memory), empty rows, a last stage shorter than 32 rows, r odd /
+    not a multiple of 16, value vectors in both memory orders.  Against scipy's product (utils.py:96-113)."""
+    rng = np.random.RandomState(len(pattern) * 100 + r)
+    N = 1000 + 13
+    if pattern == "ragged_band":
+        A = _penta(N, rng).tolil()
+        drop = rng.rand(N) < 0.3
+        for i in np.nonzero(drop)[0]:
+            if 2 <= i < N - 2:
+                A[i, i - 2] = 0.0
+                A[i, i + 1] = 0.0
+        A = csr_matrix(A)
+    elif pattern == "wide":
+        rows = np.repeat(np.arange(N), 6)
+        cols = rng.randint(0, N, size=rows.size)
+        A = csr_matrix((rng.standard_normal(rows.size), (rows, cols)), shape=(N, N))
+    elif pattern == "mixed":
+        A = _penta(N, rng).tolil()
+        for i in rng.choice(N, size=12, replace=False):
+            A[i, (i + N // 2) % N] = 1.5
+        A = csr_matrix(A)
+    else:
+        A = _penta(N, rng).tolil()
+        for i in (0, 5, 6, 7, 500, N - 1):
+            A[i, :] = 0.0
+        A = csr_matrix(A)
+    A.eliminate_zeros()
+    A.sum_duplicates()
+    A.sort_indices()
+    V, _ = np.linalg.qr(rng.standard_normal((N, r)))
+    ip, ix = ops.to_device_index(A.indptr), ops.to_device_index(A.indices)
+    Vd = ops.to_device(V)
+    AN = ops.project_csr(ip, ix, ops.to_device(A.data), Vd).cpu().numpy()
+    ref = V.T @ (A @ V)
+    assert _rel(AN, ref) < 1e-13
+    vals = A.data[:, None] * (1.0 + 0.1 * np.arange(3))[None, :]          # three value vectors on the pattern
+    for arr in (np.ascontiguousarray(vals), np.asfortranarray(vals)):
+        ANb = ops.project_csr_batched(ip, ix, ops.to_device(arr), Vd).cpu().numpy()
+        for b in range(3):
+            assert _rel(ANb[b], (1.0 + 0.1 * b) * ref) < 1e-13
+
+
 def test_project_csr_golden_and_batched(ops, golden_deim):
     g = golden_deim
     ip, ix = ops.to_device_index(g["csr_indptr"]), ops.to_device_index(g["csr_indices"])
