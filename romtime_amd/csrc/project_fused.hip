@@ -58,6 +58,7 @@ constexpr int WROWS = 48;     // V rows kept in LDS per stage (banded FE operato
 constexpr int EMAX = PT;      // entries of one stage staged through LDS (one per thread)
 
 // == 16 (mod 32) doubles: conflict-free ds_read_b64 of the MFMA operands (16 tr already is for odd tr)
+__host__ __device__ constexpr bool separate_a(int tr) { return tr <= 4; }   // see project_wave
 __host__ __device__ constexpr int stride_of(int tr) { return 16 * tr + ((tr & 1) ? 0 : 16); }
 
 // Everything a stage needs to start its loads, in one wave-uniform 16-byte record (one scalar load, issued a
@@ -172,7 +173,12 @@ __device__ __forceinline__ void project_wave(const ProjParams& p, const StageRec
   constexpr int U = TR <= 2 ? 6 : (TR <= 4 ? 3 : 2);          // entries per gather chunk (2 U TR transient VGPRs)
   static_assert(U <= EPAD, "a chunk may overrun the staged entries by U - 1");
   double* sW = sm;                                            // [WROWS][STRIDE]  window of V rows
-  double* sB = sm + WROWS * STRIDE;                           // [PK][STRIDE]     rows of A_b V
+  // r <= 64: the stage's own rows are copied to sA, so that the next window can be committed while the MFMAs run -
+  // two barriers per stage instead of three (r = 64: 0.69 -> 0.64 ms per 32 vectors, r = 40: 0.52 -> 0.49).  At
+  // r = 80 the copy's registers spill and the kernel loses 3 %: there the A operand is read out of the window.
+  constexpr bool SEP_A = separate_a(TR);
+  double* sA = sm + WROWS * STRIDE;                           // [PK][STRIDE]     the stage's own V rows (SEP_A)
+  double* sB = sA + (SEP_A ? PK * STRIDE : 0);                // [PK][STRIDE]     rows of A_b V (B operand)
   Entry* sEnt = reinterpret_cast<Entry*>(sB + PK * STRIDE);   // [EMAX + EPAD]
   const int tid = threadIdx.x, lane = tid & 63;
   const int l15 = lane & 15, l4 = lane >> 4;
@@ -285,7 +291,8 @@ __device__ __forceinline__ void project_wave(const ProjParams& p, const StageRec
   const char* sWc = reinterpret_cast<const char*>(sW) + jg * sizeof(double);
   double* brow = sB + kk * STRIDE + jg;
   const double* lB = sB + l4 * STRIDE + l15 + 16 * b0.j0;
-  const double* lA0 = sW + l4 * STRIDE + l15 + 16 * b0.i0;
+  const double* lA0 = (SEP_A ? sA : sW) + l4 * STRIDE + l15 + 16 * b0.i0;
+  constexpr int NAP = (PK + RPP - 1) / RPP;                   // passes of the copy of the stage's own rows
   __builtin_amdgcn_s_setprio(3);
   for (int st = st0; st < st1; ++st) {
     const int k0 = st * PK;
@@ -294,6 +301,19 @@ __device__ __forceinline__ void project_wave(const ProjParams& p, const StageRec
       r1 = r2;                                    // loaded one stage ago
       if (st + 2 < st1) r2 = rec[st + 2];       // for the next iteration
       if (!PF_ABLATE(64)) fetch(k0 + PK, r1);
+    }
+    if constexpr (SEP_A) {   // A operand: window rows k0 - lo .. k0 - lo + PK - 1, copied LDS -> LDS
+      if (RPP * PAIRS == PT || wrow < RPP) {
+        const double* src = w_lds + (k0 - c_lo) * STRIDE;
+        double* dst = sA + (w_lds - sW);
+        d2 t[NAP];
+#pragma unroll
+        for (int q = 0; q < NAP; ++q)
+          if (RPP * (q + 1) <= PK || wrow < PK - RPP * q) t[q] = *reinterpret_cast<const d2*>(src + q * RPP * STRIDE);
+#pragma unroll
+        for (int q = 0; q < NAP; ++q)
+          if (RPP * (q + 1) <= PK || wrow < PK - RPP * q) *reinterpret_cast<d2*>(dst + q * RPP * STRIDE) = t[q];
+      }
     }
     // B operand: rows of A_b V.  The entries of a row are taken U at a time: U entry reads, then their U TR
     // window reads, then the FMAs - two LDS round trips per chunk (one read after another costs four per entry).
@@ -360,7 +380,7 @@ __device__ __forceinline__ void project_wave(const ProjParams& p, const StageRec
 #endif
     if constexpr (NT > 0) if (!PF_ABLATE(32)) {
       // operands of k-step k4 + 1 are read before the MFMAs of k-step k4 are issued
-      const double* lA = lA0 + (k0 - c_lo) * STRIDE;  // LDS row of DoF k0 (+ this lane's k)
+      const double* lA = SEP_A ? lA0 : lA0 + (k0 - c_lo) * STRIDE;  // LDS row of DoF k0 (+ this lane's k)
       double a[2][NI], bq[2][NJ];
 #pragma unroll
       for (int i = 0; i < NI; ++i) a[0][i] = lA[16 * i];
@@ -389,9 +409,14 @@ __device__ __forceinline__ void project_wave(const ProjParams& p, const StageRec
       g_dbg[blockIdx.x * 20] = __builtin_amdgcn_s_getreg((31 << 11) | 4) | ((unsigned long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) << 32);
     }
 #endif
-    __builtin_amdgcn_s_setprio(3);   // gather, fetch and commit phases win the issue slot over the other workgroup's MFMAs
-    __syncthreads();
-    if (more) commit(r1);
+    if constexpr (SEP_A) {
+      if (more) commit(r1);            // at the MFMA phase's priority: raising it first cost 5 % at r = 64
+      __builtin_amdgcn_s_setprio(3);   // the gather and fetch phase wins the issue slot over the other workgroup's MFMAs
+    } else {
+      __syncthreads();                 // the window is the A operand: every wave's MFMAs first
+      if (more) commit(r1);
+      __builtin_amdgcn_s_setprio(3);   // the gather and fetch phase wins the issue slot over the other workgroup's MFMAs
+    }
     __syncthreads();
   }
   double* out = p.slab + ((long)b * p.S + s) * ((long)r * r);
@@ -412,7 +437,7 @@ __global__ __launch_bounds__(PT, TR <= 5 ? 4 : 2) void project_fused_kernel(cons
   extern __shared__ __attribute__((aligned(16))) double sm[];
   // a short last stage lets the A operand reach rows past the window (they only meet zero rows of B, but must be
   // finite): no LDS word is ever read uninitialised; the entries behind the staged ones stay zero
-  constexpr int words = (WROWS + PK) * stride_of(TR) + 2 * (EMAX + EPAD);
+  constexpr int words = (WROWS + (separate_a(TR) ? 2 : 1) * PK) * stride_of(TR) + 2 * (EMAX + EPAD);
   for (int i = threadIdx.x; i < words; i += PT) sm[i] = 0.0;
   __syncthreads();
   switch (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) {  // one code path per wave: its tiles are constants
@@ -462,15 +487,15 @@ int rt_project_stage_table(rt_ctx* ctx, const int64_t* indptr, const int64_t* in
 
 template <int TR>
 static constexpr size_t fused_lds() {
-  return sizeof(double) * (size_t)(WROWS + PK) * stride_of(TR) + sizeof(Entry) * (EMAX + EPAD);
+  return sizeof(double) * (size_t)(WROWS + (separate_a(TR) ? 2 : 1) * PK) * stride_of(TR) + sizeof(Entry) * (EMAX + EPAD);
 }
 
 // workgroups of project_fused_kernel<TR> that fit one CU (LDS and registers), asked of the runtime once per TR
 template <int TR>
 static int fused_blocks_per_cu(rt_ctx* ctx, int* out) {
   static int cached = 0;  // occupancy is a property of the kernel on gfx950, the same on every device of the node
-  RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&project_fused_kernel<TR, false>), 104 * 1024));
-  RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&project_fused_kernel<TR, true>), 104 * 1024));
+  RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&project_fused_kernel<TR, false>), 136 * 1024));
+  RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&project_fused_kernel<TR, true>), 136 * 1024));
   if (cached == 0) {
     int nb = 0;
     RT_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, project_fused_kernel<TR, false>, PT, fused_lds<TR>()));
