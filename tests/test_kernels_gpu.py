@@ -404,6 +404,45 @@ def test_hyper_reduced_sweep_synthetic_and_singular_system(ops):
             np.testing.assert_allclose(uD[b], uN[b], rtol=0, atol=1e-12 * np.abs(uN[b]).max())
 
 
+def test_sweeps_beyond_the_tracked_solve(ops):
+    """r = 96 > 80: the three padded matrices of the inverse tracking do not fit the LDS, both sweeps take their
+    other route (right-hand side kernel, pivoted LU, step closed by its own kernels) - same answers as the oracle."""
+    from romtime_amd.sweep import hrom_bdf_sweep, rom_bdf_sweep
+    from romtime_amd.testing.mock import AffineBurgers
+
+    rng = np.random.RandomState(7)
+    r, nt, n_mu, dt = 96, 5, 2, 1e-2
+    spd = lambda: (lambda a: a @ a.T + r * np.eye(r))(rng.standard_normal((r, r)))
+
+    def matrix_term(m, base):
+        cols = np.concatenate([base.reshape(-1, 1), 0.05 * rng.standard_normal((r * r, m - 1))], axis=1)
+        PT_U, _ = np.linalg.qr(rng.standard_normal((m, m)))
+        theta = np.concatenate([1.0 + 0.1 * rng.standard_normal((nt, n_mu, 1)), 0.1 * rng.standard_normal((nt, n_mu, m - 1))], axis=-1)
+        return dict(PT_U=PT_U, basis_rom=cols, F=theta @ PT_U.T)
+
+    mass, lin = matrix_term(3, spd()), [matrix_term(4, spd())]
+    PTn, _ = np.linalg.qr(rng.standard_normal((5, 5)))
+    nl = dict(PT_U=PTn, basis_rom=0.3 * rng.standard_normal((r * r, 5)), W=0.2 * rng.standard_normal((5, r)),
+              C=0.1 * rng.standard_normal((nt, n_mu, 5)), S=1.0 + 0.1 * rng.standard_normal((nt, n_mu)))
+    PTf, _ = np.linalg.qr(rng.standard_normal((3, 3)))
+    rhs = [dict(PT_U=PTf, basis_rom=rng.standard_normal((r, 3)), F=rng.standard_normal((nt, n_mu, 3)))]
+    uN = hrom_bdf_sweep(mass, lin, nl, rhs, dt, bdf2=True).cpu().numpy()
+    for b in range(n_mu):
+        ref = oracle.hrom_solve(mass, lin, nl, rhs, b, r, nt, dt, True)
+        assert np.linalg.norm(uN[b].T - ref) <= 1e-10 * np.linalg.norm(ref), b
+
+    fom = AffineBurgers(N=3000, nt=6, dt=2e-3, bdf2=True, seed=3)
+    xs = (np.arange(fom.Nh) + 0.5) / fom.Nh
+    V, _ = np.linalg.qr(np.stack([np.sin((k + 1) * np.pi * xs) for k in range(r)], axis=1) + 1e-3 * rng.standard_normal((fom.Nh, r)))
+    mus = [dict(alpha=0.5, beta=1.0, delta=0.3, omega=7.0), dict(alpha=0.7, beta=0.9, delta=0.35, omega=8.0)]
+    d = fom.descriptor(mus)
+    uD = rom_bdf_sweep(V, d["indptr"], d["indices"], d["mass"], d["terms"], d["term_coef"], d["tril"], d["rhs_terms"],
+                       d["rhs_coef"], d["dt"], bdf2=True).cpu().numpy()
+    for i, mu in enumerate(mus):
+        ref_rom, _ = oracle.rom_solve_nonlinear(fom, V, mu, solver=np.linalg.solve)
+        assert np.linalg.norm(uD[i].T - ref_rom) <= 1e-10 * np.linalg.norm(ref_rom), i
+
+
 @pytest.mark.parametrize("N,n,k", [(5000, 24, 200), (40000, 8, 512), (3001, 33, 70)])
 def test_gemm_nn_accumulate(ops, N, n, k):
     """out = beta out + alpha X T in the GEMM's epilogue (rt_gemm_nn_axpby): the deflation update X -= Q (Q^T X)."""
