@@ -71,7 +71,8 @@ int rt_last_gemm_ms(rt_ctx* ctx, double* ms);
 /* Event counters kept on the device by the kernels themselves (nothing on the hot path waits for them); reading one
  * synchronises the ctx stream.  Names: "eig_timeouts" (hand-offs of the small eigensolver that hit their wall-clock
  * bound: results of that call were invalid and the caller took another route), "eig_one_xcd" / "eig_general_form"
- * (tridiagonalisations that ran each hand-off form), "sweep_newton_iterations", "sweep_restarts",
+ * (tridiagonalisations that ran each hand-off form), "gram_off_xcd" (workgroups of the snapshot Gram kernel that ran on
+ * another XCD than the one their K range was laid out for: should stay 0), "sweep_newton_iterations", "sweep_restarts",
  * "sweep_lu_fallbacks", "sweep_solves" (the four numbers of rt_last_sweep_stats). */
 int rt_ctx_get_counter(rt_ctx* ctx, const char* name, int64_t* value);
 /* The same for the most recent launch of the snapshot Gram kernel (rt_gram, n >= 97, long X): its own event pair,

@@ -280,7 +280,7 @@ int rt_ctx_get_counter(rt_ctx* ctx, const char* name, int64_t* value) {
   const std::string key(name);
   static const struct { const char* name; int slot; } table[] = {
       {"eig_timeouts", RT_CNT_EIG_TIMEOUT}, {"eig_general_form", RT_CNT_EIG_GENERAL_FORM},
-      {"eig_one_xcd", RT_CNT_EIG_ONE_XCD}, {"sweep_newton_iterations", RT_CNT_NS_ITER},
+      {"eig_one_xcd", RT_CNT_EIG_ONE_XCD}, {"gram_off_xcd", RT_CNT_GRAM_OFF_XCD}, {"sweep_newton_iterations", RT_CNT_NS_ITER},
       {"sweep_restarts", RT_CNT_NS_RESTART}, {"sweep_lu_fallbacks", RT_CNT_LU_FALLBACK}, {"sweep_solves", RT_CNT_SOLVES}};
   for (const auto& t : table)
     if (key == t.name) {

@@ -46,6 +46,7 @@ enum {
   RT_CNT_EIG_TIMEOUT = 0,       // hand-offs of the tridiagonalisation that hit the wall-clock bound
   RT_CNT_EIG_GENERAL_FORM = 1,  // tridiagonalisations that ran the write-through hand-off
   RT_CNT_EIG_ONE_XCD = 2,       // ... the one-XCD hand-off
+  RT_CNT_GRAM_OFF_XCD = 3,      // workgroups of the snapshot Gram kernel that ran on another XCD than blockIdx % 8
   RT_CNT_NS_ITER = 4,           // online sweep: Newton-Schulz iterations (zeroed at the start of every sweep)
   RT_CNT_NS_RESTART = 5,        // ... systems restarted from K^T / (|K|_1 |K|_inf)
   RT_CNT_LU_FALLBACK = 6,       // ... systems handed to the pivoted LU

@@ -36,6 +36,7 @@ struct GramParams {
   long K, n, kx;      // rows, columns, rows per XCD range (multiple of KB)
   double* slab;       // [8][nslots][128*128]
   int nslots, tiles1, vec, flags;  // flags: 1 = s_setprio around the MFMA block, 2 = stagger odd wave slots
+  long* counters;      // rt_ctx::dev_counters
   unsigned char slot_tm[MAX_SLOTS], slot_tn[MAX_SLOTS], slot_q[MAX_SLOTS], slot_S[MAX_SLOTS];
 };
 
@@ -58,6 +59,10 @@ __global__ __launch_bounds__(GT, 4) void gram128_kernel(const GramParams p) {
 
   const int tid = threadIdx.x;
   const int x = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  // the XCD-local K ranges rest on workgroup i running on XCD i % 8: count the ones that do not (rt_ctx_get_counter
+  // "gram_off_xcd"; a CU-masked stream or a driver change could break the rule, the L2 reuse would go with it)
+  if (tid == 0 && (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) != x)
+    atomicAdd(reinterpret_cast<unsigned long long*>(&p.counters[RT_CNT_GRAM_OFF_XCD]), 1ull);
   // (a byte table in the kernel arguments indexed by a run-time slot is fetched with VECTOR loads: without the
   // readfirstlane every quantity derived from these four - tile origin, K range, panel pointers - lives in VGPRs and
   // all the "uniform" arithmetic of the loop is VALU work, which FP64 MFMAs cannot overlap with)
@@ -282,6 +287,7 @@ int rt_gram128(rt_ctx* ctx, const double* X, int64_t ks, int64_t ms, int64_t K, 
   if ((!kc && (long)ks * 8 * 8 >= (1L << 31)) || (kc && (long)ms * 64 * 8 >= (1L << 31))) p.vec = 0;
   static const int env_flags = [] { const char* e = getenv("ROMTIME_GRAM_FLAGS"); return e ? atoi(e) : 1; }();
   p.flags = env_flags;
+  p.counters = ctx->dev_counters;
 
   const int S_off = n_off ? slots_max / n_off : 0;   // sub-splits per off-diagonal tile per XCD
   // too little work per workgroup: slab traffic and two launches would dominate
