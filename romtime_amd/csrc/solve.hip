@@ -19,6 +19,7 @@
 #include "tile_layout.h"
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
 
 namespace {
 
@@ -221,7 +222,31 @@ __global__ __launch_bounds__(NS_THREADS) void newton_solve_kernel(const double* 
   // K, the carried inverse and (when the right-hand side is formed here) M_N come in together: one round of global
   // loads, M_N parked in sT until the first product needs the space
   const double* Mb = rq.MN ? rq.MN + (size_t)blockIdx.x * (rq.mn_stride < 0 ? (long)r * r : rq.mn_stride) : nullptr;
-  {
+  const bool wide_ok = (r == rp) && ((reinterpret_cast<size_t>(Kb) | reinterpret_cast<size_t>(Xb) | reinterpret_cast<size_t>(Mb)) & 15) == 0;
+  if (wide_ok) {
+    // r a multiple of 16: a row is r / 2 <= 40 pairs, one 16-byte load per lane and row; the <= 10 rows of a wave
+    // for all three matrices are in flight together
+    constexpr int QMAX = 10;
+    d2 kv[QMAX], xv[QMAX], mv[QMAX];
+    const int j = 2 * lane;
+#pragma unroll
+    for (int q = 0; q < QMAX; ++q) {
+      const int i = wid + 8 * q;
+      const bool in = i < r && j < r;
+      kv[q] = in ? *reinterpret_cast<const d2*>(Kb + i * r + j) : d2{0.0, 0.0};
+      xv[q] = (in && have_prev) ? *reinterpret_cast<const d2*>(Xb + i * r + j) : d2{i == j ? 1.0 : 0.0, i == j + 1 ? 1.0 : 0.0};
+      mv[q] = (in && Mb) ? *reinterpret_cast<const d2*>(Mb + i * r + j) : d2{0.0, 0.0};
+    }
+#pragma unroll
+    for (int q = 0; q < QMAX; ++q) {
+      const int i = wid + 8 * q;
+      if (i < r && j < r) {
+        *reinterpret_cast<d2*>(sK + i * S + j) = kv[q];
+        *reinterpret_cast<d2*>(sX + i * S + j) = xv[q];
+        if (Mb) *reinterpret_cast<d2*>(sT + i * S + j) = mv[q];
+      }
+    }
+  } else {
     // rp <= 80: a wave has at most 10 rows (i = wid + 8 q) of at most 2 x 64 columns.  Fixed trip counts, loads of
     // half the rows issued before any LDS store: a loop over runtime bounds went load - wait - store twenty times
     constexpr int QH = 5;
@@ -407,8 +432,23 @@ __global__ __launch_bounds__(NS_THREADS) void newton_solve_kernel(const double* 
   __syncthreads();
   matvec(sX, s_vec[2], s_vec[1]);
   if (tid < r) rb[tid] = x + s_vec[1][tid];
-  for (int i = wid; i < r; i += NS_THREADS / 64)
-    for (int j = lane; j < r; j += 64) Xb[i * r + j] = sX[i * S + j];
+  if (wide_ok) {   // the refreshed inverse goes back the way it came: one 16-byte store per lane and row
+    const int j = 2 * lane;
+    d2 xv[10];
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+      const int i = wid + 8 * q;
+      if (i < r && j < r) xv[q] = *reinterpret_cast<const d2*>(sX + i * S + j);
+    }
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+      const int i = wid + 8 * q;
+      if (i < r && j < r) *reinterpret_cast<d2*>(Xb + i * r + j) = xv[q];
+    }
+  } else {
+    for (int i = wid; i < r; i += NS_THREADS / 64)
+      for (int j = lane; j < r; j += 64) Xb[i * r + j] = sX[i * S + j];
+  }
   if (info && tid == 0) info[blockIdx.x] = status;
   if (adv.enabled) {  // the hyper-reduced sweep's end of step for this system
     __syncthreads();  // rb is complete and visible in this workgroup
