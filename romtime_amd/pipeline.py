@@ -37,6 +37,7 @@ from . import _lib, ops, pod
 _p = C.c_void_p
 
 
+SMALL_SET = 150_000_000   # rows x columns below which a set takes the regular route (see run())
 _STREAMS: dict = {}
 
 
@@ -76,14 +77,18 @@ atexit.register(shutdown)
 
 
 class PodPipeline:
-    def __init__(self, eig_cus_per_xcd: int = 4, device=None, group=None, eig_first_cu: int = 0, gram_range=None):
+    def __init__(self, eig_cus_per_xcd: int = 4, device=None, group=None, eig_first_cu: int = 0, gram_range=None,
+                 small_set=None):
         """``eig_cus_per_xcd``: CUs of every XCD given to the eigensolver stream (4 -> 32 CUs: a CU per cooperating
         workgroup; 4 and 8 keep the shader engines of an XCD evenly loaded, other values measured slower).
         ``group``: torch.distributed process group of a row-sharded run - the Gram matrices are summed over it on stream
         G (one all-reduce per snapshot set), the small eigenproblem is replicated on every rank (identical inputs,
         deterministic kernels: identical outputs).
         ``eig_first_cu`` / ``gram_range`` = (first, count): explicit per-XCD CU ranges of the two streams, for processes that
-        share one GPU (their eigensolver teams must not share CUs: a team spins until all its workgroups are resident)."""
+        share one GPU (their eigensolver teams must not share CUs: a team spins until all its workgroups are resident).
+        ``small_set``: sets with fewer than this many entries (global rows x columns; default SMALL_SET) take the regular
+        route when their turn comes - the overlap does not pay for them (see run())."""
+        self.small_set = SMALL_SET if small_set is None else int(small_set)
         if not torch.cuda.is_available():
             raise _lib.RomtimeHipError("no MI355X visible: romtime_amd's hot path runs on the GPU only")
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
@@ -261,7 +266,13 @@ class PodPipeline:
             n = X.shape[1]
             # what the eigensolver's CU share cannot hold (the 128-workgroup team of n > 512) or the device eigensolver
             # does not take (n < 3) goes the regular route when its turn comes; the order of the results is kept
-            item["direct"] = not (3 <= n <= 512)
+            # ... and so do sets too small for the overlap to pay: the eigensolve (about 3.5 us per column on the
+            # 32-CU share, where its hand-offs cross XCDs) outlasts a Gram of N n^2 / 6e13 s when N n < 2e8, and the
+            # whole chip runs such a POD faster on its own (16 sets of 1e5 x 256: 1.34 ms each one after the other,
+            # 1.61 through the streams; tools/bench_configs.py c2pipe).  With row shards every rank sees the same
+            # (global) shape rule, so the collectives stay matched.
+            rows = X.shape[0] * self.world
+            item["direct"] = not (3 <= n <= 512) or rows * n < self.small_set
             if not item["direct"]:
                 self._gram(item)
                 self._eig(item)

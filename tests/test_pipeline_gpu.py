@@ -35,7 +35,7 @@ def test_pipeline_matches_single_pods_and_oracle():
             np.asfortranarray(_matrix(rng, 7001, 200, 1.0)), _matrix(rng, 4096, 512, 3.0), _matrix(rng, 9000, 96, 1.5) * 7.0,
             _matrix(rng, 3000, 600, 2.0)]                                                                   # n > 512: regular route
     dev = [ops.to_device(m) for m in mats]
-    pipe = PodPipeline()
+    pipe = PodPipeline(small_set=0)      # the test's sets are small: keep them on the streams
     outs = pipe.map(dev, num=k, normalize=True)
     assert len(outs) == len(mats) and pipe.recomputed == 2
     for X, Xd, out in zip(mats, dev, outs):
@@ -107,7 +107,7 @@ def _worker(rank, world, port, mats, k, ret):
         from romtime_amd.pipeline import PodPipeline
 
         # two processes on ONE GPU: eigensolver teams on disjoint CUs (a team spins until it is resident), Gram streams shared
-        pipe = PodPipeline(group=dist.group.WORLD, eig_first_cu=4 * rank, gram_range=(8, 24))
+        pipe = PodPipeline(group=dist.group.WORLD, eig_first_cu=4 * rank, gram_range=(8, 24), small_set=0)
         local = [torch.from_numpy(np.array_split(m, world)[rank]).cuda() for m in mats]
         outs = pipe.map(local, num=k, normalize=True)
         ret[rank] = [dict(Q=o["Q"].cpu().numpy(), s=o["s"], r=o["r"]) for o in outs]

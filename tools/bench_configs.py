@@ -69,6 +69,33 @@ def c2():
                 passes=out["passes"])
 
 
+def c2pipe(sets=16):
+    """The tree walks' pattern (rom.py:317-406, deim.py:279-397): many independent small PODs.  The same C2-sized sets
+    one after the other and through the CU-partitioned pipeline (eigensolve of set i beside the Gram of set i+1)."""
+    from romtime_amd import pipeline
+
+    N, n, r = 100_000, 256, 40
+    g = torch.Generator(device="cuda").manual_seed(2)
+    s = torch.from_numpy(10.0 ** (-6.0 * np.arange(n) / (n - 1))).cuda()
+    Xs = []
+    for _ in range(sets):
+        V0, _ = torch.linalg.qr(torch.randn((n, n), dtype=torch.float64, device="cuda", generator=g))
+        Xs.append((torch.randn((N, n), dtype=torch.float64, device="cuda", generator=g) / np.sqrt(N)) @ (s[:, None] * V0.T))
+    ms_seq, outs = wall_time(lambda: [pod.pod_device(X, num=r, normalize=True) for X in Xs], reps=3)
+    pipe = pipeline.PodPipeline(small_set=0)     # forced onto the streams; by default such small sets take the regular route
+    ms_pipe, pouts = wall_time(lambda: pipe.map(Xs, num=r, normalize=True), reps=3)
+    worst = 0.0
+    for a, b in zip(outs, pouts):
+        Qa, Qb = a["Q"], b["Q"]
+        worst = max(worst, float(torch.linalg.matrix_norm(Qb @ (Qb.T @ Qa) - Qa, 2)))
+    res = dict(config=f"C2 x {sets}: independent PODs of 1e5x256 r40, one after the other vs PodPipeline.map",
+               sequential_ms_per_pod=ms_seq / sets, forced_pipeline_ms_per_pod=ms_pipe / sets,
+               sequential_dof_per_s=N * n * sets / ms_seq * 1e3, recomputed=int(pipe.recomputed),
+               subspace_dist_pipeline_vs_sequential=worst)
+    pipeline.shutdown()
+    return res
+
+
 def c4():
     N, nnz_row, n_ops, m, r = 100_000, 5, 200, 120, 80
     rng = np.random.RandomState(4)
@@ -247,6 +274,6 @@ def c5h(nt=2000, n_mu=32, N=100_000, r=80, m_lin=40, m_nl=120, m_rhs=20):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["c2", "c4", "c5", "c5sweep", "c5h"]
+    which = sys.argv[1:] or ["c2", "c2pipe", "c4", "c5", "c5sweep", "c5h"]
     for w in which:
-        print(json.dumps({"c2": c2, "c4": c4, "c5": c5, "c5sweep": c5sweep, "c5h": c5h}[w]()), flush=True)
+        print(json.dumps({"c2": c2, "c2pipe": c2pipe, "c4": c4, "c5": c5, "c5sweep": c5sweep, "c5h": c5h}[w]()), flush=True)
