@@ -54,6 +54,9 @@ int rt_ctx_set_profile(rt_ctx* ctx, int on);
 /* Named switches.  "eig_one_xcd" (default 1): the small eigensolver may place its cooperating workgroups on one
  * XCD and hand off through that XCD's L2 (placement is verified on the device); it needs every CU of that XCD,
  * so processes that share a GPU turn it off (a hand-off timeout of rt_sym_eig_values is the symptom).
+ * "eig_xcd" (default 0, 0 .. 7): the XCD that form puts its workgroups on.  Contexts with different values (each on
+ * a stream of its own) run their eigensolves side by side - eight small PODs at a time, romtime_amd.pipeline.PodLanes;
+ * two eigensolves in flight on the SAME XCD would starve each other of CUs (they end in the hand-off's time-out).
  * "sweep_graph" (default 0): rt_hrom_bdf_sweep captures one time step as a hipGraph (its kernels read the step from a
  * device counter) and replays it for steps 1 .. nt-1 instead of launching two kernels per step; for hosts that
  * cannot keep ahead of the device.  The call then returns only when the sweep has finished. */
@@ -107,6 +110,15 @@ int rt_gram_scale(rt_ctx* ctx, double* G, int64_t n, double* colnorm, int normal
 int rt_pod_orth(rt_ctx* ctx, const double* X, int64_t n_rows, int64_t n_cols, int64_t ld, int layout, int64_t num,
                 double tol, int normalize, double* Q, int64_t q_cols, int64_t* r_out, double* s_host,
                 double* energy_host, int* levels_out);
+
+/* One single-pass POD, ENQUEUED on the ctx stream and not waited for: Gram matrix, scaling, all eigenvalues, the k
+ * leading eigenvectors, back-projection Q (n_rows x k, row-major) = X D^-1 W S^-1.  The decisions `orth` takes from the
+ * spectrum (deflated levels for deep spectra, Rayleigh-Ritz for clusters, the zero-norm error) are the caller's, after
+ * the fact: lam (n_cols, descending, device), status2 (device ints: [0] eigensolver hand-off status, [1] zero-norm
+ * flag), colnorm (n_cols).  G (n x n), Z and Zs (n x k) are work space the caller owns.  One host call per snapshot set:
+ * what lets romtime_amd.pipeline.PodLanes keep eight small PODs on the chip (eight contexts, "eig_xcd" 0 .. 7). */
+int rt_pod_enqueue(rt_ctx* ctx, const double* X, int64_t n_rows, int64_t n_cols, int64_t ld, int layout, int64_t k,
+                   int normalize, double* G, double* colnorm, double* lam, int* status2, double* Z, double* Zs, double* Q);
 
 /* Zs (n x k row-major) = D^-1 W S^-1: W = Z (n x k eigenvectors of the Gram matrix, rt_sym_eig_vectors), D = diag(colnorm)
  * (NULL: identity, normalize == False), S_j = sqrt(lam_j) (device eigenvalues; S^-1 = 0 where lam_j <= 0).  The matrix the

@@ -41,6 +41,7 @@ SIGNATURES = {
     "rt_gram": (_int, [_p, _p, _i64, _i64, _i64, _int, _p]),
     "rt_gram_scale": (_int, [_p, _p, _i64, _p, _int, _p]),
     "rt_pod_backproject_weights": (_int, [_p, _p, _i64, _i64, _p, _p, _p]),
+    "rt_pod_enqueue": (_int, [_p, _p, _i64, _i64, _i64, _int, _i64, _int, _p, _p, _p, _p, _p, _p, _p]),
     "rt_pod_orth": (_int, [_p, _p, _i64, _i64, _i64, _int, _i64, C.c_double, _int, _p, _i64, C.POINTER(_i64), _p, _p,
                            C.POINTER(_int)]),
     "rt_gemm_tn": (_int, [_p, _p, _i64, _int, _p, _i64, _int, _i64, _i64, _i64, _p, _i64]),

@@ -259,6 +259,14 @@ int rt_ctx_set_option(rt_ctx* ctx, const char* name, int value) {
     ctx->eig_one_xcd = value != 0;
     return RT_OK;
   }
+  if (key == "eig_xcd") {
+    if (value < 0 || value > 7) {
+      ctx->err = "rt_ctx_set_option: eig_xcd must be 0 .. 7";
+      return RT_ERR_ARG;
+    }
+    ctx->eig_xcd = value;
+    return RT_OK;
+  }
   if (key == "sweep_graph") {
     ctx->sweep_graph = value != 0;
     return RT_OK;

@@ -27,6 +27,7 @@ struct rt_ctx {
   bool gev_valid = false;
   bool sweep_graph = false;         // rt_hrom_bdf_sweep replays steps 1.. as a hipGraph (rt_ctx_set_option)
   bool eig_one_xcd = true;          // allow the one-XCD form of the eigensolver's hand-off (rt_ctx_set_option)
+  int eig_xcd = 0;                  // ... and the XCD its workers are put on ("eig_xcd": eigensolves on different XCDs run side by side)
   // state handed from rt_sym_eig_values to rt_sym_eig_vectors (pointers into the composite arena)
   struct {
     const double *d = nullptr, *e = nullptr, *V = nullptr, *tau = nullptr;

@@ -79,6 +79,21 @@ extern "C" int rt_pod_backproject_weights(rt_ctx* ctx, const double* Z, int64_t 
   return RT_OK;
 }
 
+extern "C" int rt_pod_enqueue(rt_ctx* ctx, const double* X, int64_t n_rows, int64_t n_cols, int64_t ld, int layout, int64_t k,
+                              int normalize, double* G, double* colnorm, double* lam, int* status2, double* Z, double* Zs,
+                              double* Q) {
+  if (!ctx) return RT_ERR_ARG;
+  RT_ARG_CHECK(ctx, X && G && colnorm && lam && status2 && Z && Zs && Q);
+  RT_ARG_CHECK(ctx, n_rows >= 1 && n_cols >= 3 && n_cols <= 1024 && k >= 1 && k <= n_cols);
+  RT_ARG_CHECK(ctx, layout == RT_ROW_MAJOR || layout == RT_COL_MAJOR);
+  RT_TRY(rt_gram(ctx, X, n_rows, n_cols, ld, layout, G));
+  RT_TRY(rt_gram_scale(ctx, G, n_cols, colnorm, normalize, status2 + 1));
+  RT_TRY(rt_sym_eig_values(ctx, G, n_cols, lam, status2));
+  RT_TRY(rt_sym_eig_vectors(ctx, n_cols, k, lam, Z));
+  RT_TRY(rt_pod_backproject_weights(ctx, Z, n_cols, k, normalize ? colnorm : nullptr, lam, Zs));
+  return rt_gemm_nn(ctx, X, ld, layout, Zs, k, n_rows, n_cols, k, Q, k, RT_ROW_MAJOR);
+}
+
 extern "C" int rt_pod_orth(rt_ctx* ctx, const double* X, int64_t n_rows, int64_t n_cols, int64_t ld, int layout, int64_t num,
                            double tol, int normalize, double* Q, int64_t q_cols, int64_t* r_out, double* s_host,
                            double* energy_host, int* levels_out) {

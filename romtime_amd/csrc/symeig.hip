@@ -44,10 +44,11 @@ struct TriParams {
   double* tau;       // n
   double* d;         // n
   double* e;         // n
-  int* flags;        // [3] = error, [8 .. 8 + tw) = XCC id of each workgroup, [SLOT0 .. SLOT0 + tw) = arrival slots
+  int* flags;        // [3] = error, [4] = worker tickets of the one-XCD form, [8 .. 8 + tw) = XCC id of each workgroup, [SLOT0 .. SLOT0 + tw) = arrival slots
   int n;
   int tw;            // cooperating workgroups
-  int spread;        // 1: launched as 8 tw blocks, only the blocks with blockIdx % 8 == 0 work (they share an XCD)
+  int spread;        // 1: launched as 8 tw blocks, only the blocks with blockIdx % 8 == xcd work (they share an XCD)
+  int xcd;
   long* counters;    // rt_ctx::dev_counters: which hand-off form ran, and time-outs (rt_ctx_get_counter)
 };
 
@@ -116,8 +117,20 @@ __device__ __forceinline__ double block_sum(double x, double* s_red) {
 template <int NM>
 __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  if (p.spread && (blockIdx.x & 7)) return;  // filler blocks: only there to put the workers on one XCD
-  const int n = p.n, TW = p.tw, tid = threadIdx.x, wg = p.spread ? blockIdx.x >> 3 : blockIdx.x, lane = tid & 63,
+  // One-XCD form: of the 16 tw blocks launched, the first tw that find themselves on XCD p.xcd become the workers
+  // (a ticket each; the rest, and everything that landed elsewhere, leave at once).  Where a block lands is observed,
+  // not derived from blockIdx: with other kernels in flight - eigensolves of other contexts on other XCDs,
+  // romtime_amd.pipeline.PodLanes - block i is not on XCD i % 8.
+  __shared__ int s_ticket;
+  if (p.spread) {
+    if (threadIdx.x == 0) {
+      const int xcc = (int)(__builtin_amdgcn_s_getreg((4 - 1) << 11 | (0 << 6) | 20) & 15u);
+      s_ticket = (xcc == p.xcd) ? __hip_atomic_fetch_add(&p.flags[4], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : p.tw;
+    }
+    __syncthreads();
+    if (s_ticket >= p.tw) return;
+  }
+  const int n = p.n, TW = p.tw, tid = threadIdx.x, wg = p.spread ? s_ticket : blockIdx.x, lane = tid & 63,
             wid = tid >> 6;
   const int RB = (n + TW - 1) / TW;
   double* A = sm;                 // RB x n, local row li <-> global row li*TW + wg
@@ -656,10 +669,11 @@ extern "C" int rt_sym_eig_values_part(rt_ctx* ctx, const double* G, int64_t n, i
   char* b8 = static_cast<char*>(base);
   TriParams tp;
   tp.G = G; tp.n = (int)n; tp.tw = tw;
-  // n <= 512: launch 8 x 32 blocks and let only every 8th work; blocks b and b + 8 go to the same XCD, so the 32
+  // n <= 512: launch 16 x 32 blocks, of which the first 32 that find themselves on XCD eig_xcd work, so the 32
   // workers can hand off through one L2 (the kernel checks HW_REG_XCC_ID and falls back to the general form).
   // ROMTIME_EIG_FLAGS=1 disables it.
   tp.spread = (!large && ctx->eig_one_xcd && !(eig_flags & 1) && ctx->num_cus / 8 >= tw) ? 1 : 0;  // a CU per worker
+  tp.xcd = ctx->eig_xcd & 7;
   tp.V = reinterpret_cast<double*>(b8 + oV); tp.P = reinterpret_cast<double*>(b8 + oP);
   tp.tau = reinterpret_cast<double*>(b8 + oT); tp.d = reinterpret_cast<double*>(b8 + oD);
   tp.e = reinterpret_cast<double*>(b8 + oE); tp.flags = reinterpret_cast<int*>(b8 + oF);
@@ -692,7 +706,7 @@ extern "C" int rt_sym_eig_values_part(rt_ctx* ctx, const double* G, int64_t n, i
     hipLaunchKernelGGL(symeig_bisect_kernel<1024>, bgrid, dim3(256), 0, st, tp.d, tp.e, (int)n, (int)first, (int)count,
                        lam, tp.flags, status, ctx->dev_counters);
   } else {
-    hipLaunchKernelGGL(symeig_tridiag_kernel<512>, dim3(tp.spread ? 8 * tw : tw), dim3(TT), lds, st, tp);
+    hipLaunchKernelGGL(symeig_tridiag_kernel<512>, dim3(tp.spread ? 16 * tw : tw), dim3(TT), lds, st, tp);
     RT_HIP_CHECK(ctx, hipGetLastError());
     hipLaunchKernelGGL(symeig_bisect_kernel<512>, bgrid, dim3(256), 0, st, tp.d, tp.e, (int)n, (int)first, (int)count,
                        lam, tp.flags, status, ctx->dev_counters);

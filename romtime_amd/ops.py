@@ -242,6 +242,23 @@ def dense_solve(K: torch.Tensor, b: torch.Tensor):
     return (bw[0] if single else bw), info
 
 
+def pod_enqueue(X: torch.Tensor, k: int, normalize: bool):
+    """One single-pass POD enqueued on the ctx stream with ONE host call (rt_pod_enqueue): returns the device tensors
+    (Q, lam, status2, colnorm) and a tuple of the work buffers to keep alive until the stream has run them."""
+    ctx = Context.current()
+    X, ld, lay = _layout(X)
+    N, n = X.shape
+    dev = X.device
+    work = torch.empty(n * n + 2 * n + 2 * n * k, dtype=torch.float64, device=dev)
+    G, colnorm, lam = work[: n * n].view(n, n), work[n * n: n * n + n], work[n * n + n: n * n + 2 * n]
+    Z, Zs = work[n * n + 2 * n: n * n + 2 * n + n * k].view(n, k), work[n * n + 2 * n + n * k:].view(n, k)
+    status2 = torch.empty(2, dtype=torch.int32, device=dev)
+    Q = torch.empty((N, k), dtype=torch.float64, device=dev)
+    ctx.check(ctx.lib.rt_pod_enqueue(ctx.handle, _ptr(X), N, n, ld, lay, k, int(bool(normalize)), _ptr(G), _ptr(colnorm),
+                                     _ptr(lam), _ptr(status2), _ptr(Z), _ptr(Zs), _ptr(Q)), "rt_pod_enqueue")
+    return Q, lam, status2, colnorm, (work, X)
+
+
 def tracked_solve(K: torch.Tensor, b: torch.Tensor, Xinv: torch.Tensor = None):
     """Solve K x = b for a batch ([B,r,r], [B,r]) with the inverse tracked in ``Xinv`` ([B,r,r], carried from call to
     call; None = first call).  Returns (x, info, Xinv).  rt_tracked_solve_batched (r <= 80)."""

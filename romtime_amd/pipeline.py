@@ -234,6 +234,7 @@ class PodPipeline:
             # what pod_device decides after the fact too: this spectrum needs deflated levels / a Rayleigh-Ritz step
             self.recomputed += 1
             return pod.pod_device(item["X"], num=item["num"], normalize=item["normalize"], group=self.group)
+        item["Q"].record_stream(torch.cuda.current_stream(self.device))   # allocated under stream G, used by the caller's
         return dict(Q=item["Q"], s=s, energy=energy, VT=None, r=k, passes=1, colnorm=item["colnorm"])
 
     # ---- driver -----------------------------------------------------------------------------------------------
@@ -309,3 +310,110 @@ class PodPipeline:
 
     def map(self, snapshot_sets, num, normalize=True, depth=2):
         return list(self.run(snapshot_sets, num, normalize=normalize, depth=depth))
+
+
+class PodLanes:
+    """Many SMALL independent PODs (the tree walks' inner loops: rom.py:317-406, deim.py:279-397): eight at a time.
+
+    A small set's time is its n x n eigensolve - 32 workgroups on ONE XCD handing columns to each other - while the
+    other seven XCDs idle.  A lane is a Context whose eigensolver works on XCD ``lane`` (option "eig_xcd") plus a
+    stream of its own; set i runs its whole chain (Gram, scaling, eigenvalues, vectors, back-projection) on lane
+    i mod 8, so eight chains are on the chip together and no two eigensolver teams ever want the same CUs.  The `num`
+    rule only, as in PodPipeline (everything is enqueued ahead of the spectrum); a set whose spectrum turns out to
+    need deflated levels or a Rayleigh-Ritz step is recomputed by ``pod.pod_device``.  Single GPU.
+    """
+
+    def __init__(self, lanes: int = 8, device=None):
+        if not torch.cuda.is_available():
+            raise _lib.RomtimeHipError("no MI355X visible: romtime_amd's hot path runs on the GPU only")
+        if not (1 <= int(lanes) <= 8):
+            raise ValueError("lanes must be 1 .. 8 (one per XCD)")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.ctx, self.streams = [], []
+        for lane in range(int(lanes)):
+            c = _lib.Context(self.device.index)
+            c.set_option("eig_xcd", lane)
+            self.ctx.append(c)
+            self.streams.append(torch.cuda.Stream(self.device))
+        self.recomputed = 0
+
+    def _enqueue(self, item, lane):
+        X, k, normalize = item["X"], item["k"], item["normalize"]
+        n = X.shape[1]
+        with self.ctx[lane].use(self.streams[lane]):
+            # one host call for the whole chain (rt_pod_enqueue): with a Python call per kernel the host, not the chip,
+            # decided how many chains were in flight
+            Q, lam_d, status2, colnorm, keep = ops.pod_enqueue(X, k, normalize)
+            head = torch.cat([lam_d, status2.to(torch.float64)])
+            item["head"] = torch.empty(n + 2, dtype=torch.float64).pin_memory()
+            item["head"].copy_(head, non_blocking=True)
+            item["Q"], item["colnorm"] = Q, colnorm
+            item["_keep"] = (keep, head, lam_d, status2)
+            item["done"] = torch.cuda.Event()
+            item["done"].record()
+
+    def _finish(self, item):
+        if item["direct"]:
+            self.recomputed += 1
+            return pod.pod_device(item["X"], num=item["num"], normalize=item["normalize"])
+        item["done"].synchronize()
+        n, k = item["X"].shape[1], item["k"]
+        head = item["head"].numpy()
+        lam, status, zero_norm = head[:n], int(head[n]), int(head[n + 1])
+        if item["normalize"] and zero_norm:
+            raise ValueError("array must not contain infs or NaNs (zero-norm snapshot with normalize=True)")
+        s = np.sqrt(np.clip(lam, 0.0, None))
+        gaps = lam[:k] - lam[1:k + 1] if k < n else np.r_[lam[:k - 1] - lam[1:k], lam[k - 1]]
+        ok = (status == 0 and s[0] > 0 and s[k - 1] >= pod.TWO_PASS_RATIO * s[0]
+              and gaps.min() >= pod.RR_GAP * max(lam[0], 1e-300) and item["X"].shape[0] >= n)
+        if not ok:
+            self.recomputed += 1
+            return pod.pod_device(item["X"], num=item["num"], normalize=item["normalize"])
+        for t in (item["Q"], item["colnorm"]):                      # allocated under the lane's stream, used by the caller's
+            t.record_stream(torch.cuda.current_stream(self.device))
+        return dict(Q=item["Q"], s=s, energy=pod._energy(s), VT=None, r=k, passes=1, colnorm=item["colnorm"])
+
+    def run(self, snapshot_sets, num, normalize=True):
+        """Generator over the results (dicts as ``pod.pod_device`` returns) of ``orth(X, num=num, normalize=normalize)``
+        for every X of ``snapshot_sets`` (float64 CUDA tensors, N x n), in order; one set per lane is in flight."""
+        if not num:
+            raise ValueError("PodLanes enqueues ahead of the spectrum: it needs `num` (pod.py:51-53)")
+        main = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(main)                       # the snapshot sets were produced on the caller's stream
+        for st in self.streams:
+            st.wait_event(ready)
+        it = iter(snapshot_sets)
+        pending = collections.deque()
+        admitted = 0
+
+        def admit():
+            nonlocal admitted
+            try:
+                X = next(it)
+            except StopIteration:
+                return False
+            if X.dim() != 2 or not X.is_cuda or X.dtype != torch.float64:
+                raise _lib.RomtimeHipError("PodLanes takes 2-D float64 CUDA tensors")
+            n = X.shape[1]
+            item = dict(X=X, num=num, k=int(min(num, n)), normalize=bool(normalize), direct=not (3 <= n <= 512))
+            if not item["direct"]:
+                self._enqueue(item, admitted % len(self.streams))
+            admitted += 1
+            pending.append(item)
+            return True
+
+        for _ in range(len(self.streams)):
+            if not admit():
+                break
+        while pending:
+            out = self._finish(pending.popleft())
+            admit()                                # the lane just freed takes the next set
+            yield out
+        done = torch.cuda.Event()
+        for st in self.streams:                    # later work on the caller's stream sees every Q
+            done.record(st)
+            main.wait_event(done)
+
+    def map(self, snapshot_sets, num, normalize=True):
+        return list(self.run(snapshot_sets, num, normalize=normalize))

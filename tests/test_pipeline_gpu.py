@@ -61,6 +61,44 @@ def test_pipeline_matches_single_pods_and_oracle():
     pipe.close()
 
 
+def test_lanes_match_single_pods_and_oracle():
+    """PodLanes: eight small PODs on the chip at a time (one eigensolver team per XCD, option "eig_xcd"; one host call per
+    chain, rt_pod_enqueue).  Same answers as pod_device and the oracle, in order, for more sets than lanes, both
+    memory orders, a deep spectrum (recomputed on the regular route) and n > 512 (regular route)."""
+    from romtime_amd import ops, pod
+    from romtime_amd._lib import Context
+    from romtime_amd.pipeline import PodLanes
+
+    rng = np.random.RandomState(11)
+    k = 5
+    mats = [_matrix(rng, 6000 + 500 * i, 64 + 16 * (i % 5), 1.0 + 0.2 * i) for i in range(19)]
+    mats[3] = np.asfortranarray(mats[3])
+    mats[7] = _matrix(rng, 9000, 96, 60.0)          # deep: regular route after the fact
+    mats[12] = _matrix(rng, 3000, 600, 2.0)         # n > 512: regular route
+    dev = [ops.to_device(m) for m in mats]
+    lanes = PodLanes()
+    outs = lanes.map(dev, num=k, normalize=True)
+    assert len(outs) == len(mats) and lanes.recomputed == 2
+    timeouts = sum(c.counter("eig_timeouts") for c in lanes.ctx)
+    assert timeouts == 0
+    assert sum(c.counter("eig_one_xcd") for c in lanes.ctx) >= len(mats) - 2     # every team found its XCD
+    for X, Xd, out in zip(mats, dev, outs):
+        single = pod.pod_device(Xd, num=k, normalize=True)
+        Qo, so, eo = oracle.orth(X, num=k, normalize=True)
+        bar = 2e-13 * so[0] + 8 * EPS * so[0] ** 2 / np.maximum(so, 1e-300)
+        assert out["r"] == k and np.all(np.abs(out["s"] - so) <= bar)
+        np.testing.assert_allclose(out["energy"], eo, rtol=1e-10)
+        Q = out["Q"].cpu().numpy()
+        assert np.abs(Q.T @ Q - np.eye(k)).max() < 1e-10
+        _same_columns(Q, single["Q"].cpu().numpy(), 1e-11)
+        _same_columns(Q, Qo, 1e-9)
+    with pytest.raises(ValueError):
+        lanes.map(dev[:1], num=None)
+    Z = ops.to_device(np.c_[mats[0][:, :5], np.zeros((mats[0].shape[0], 1))])
+    with pytest.raises(ValueError):                                   # zero-norm column + normalize, as orth does
+        lanes.map([Z], num=3, normalize=True)
+
+
 def test_cu_partition_abi():
     """rt_stream_create_cu_range / "cu_limit": argument checks, and kernels on a masked stream give the same numbers."""
     import ctypes as C

@@ -84,13 +84,21 @@ def c2pipe(sets=16):
     ms_seq, outs = wall_time(lambda: [pod.pod_device(X, num=r, normalize=True) for X in Xs], reps=3)
     pipe = pipeline.PodPipeline(small_set=0)     # forced onto the streams; by default such small sets take the regular route
     ms_pipe, pouts = wall_time(lambda: pipe.map(Xs, num=r, normalize=True), reps=3)
+    lanes = pipeline.PodLanes()
+    ms_lanes, louts = wall_time(lambda: lanes.map(Xs, num=r, normalize=True), reps=3)
+    worst_l = 0.0
+    for a, b in zip(outs, louts):
+        Qa, Qb = a["Q"], b["Q"]
+        worst_l = max(worst_l, float(torch.linalg.matrix_norm(Qb @ (Qb.T @ Qa) - Qa, 2)))
     worst = 0.0
     for a, b in zip(outs, pouts):
         Qa, Qb = a["Q"], b["Q"]
         worst = max(worst, float(torch.linalg.matrix_norm(Qb @ (Qb.T @ Qa) - Qa, 2)))
-    res = dict(config=f"C2 x {sets}: independent PODs of 1e5x256 r40, one after the other vs PodPipeline.map",
+    res = dict(config=f"C2 x {sets}: independent PODs of 1e5x256 r40, one after the other / PodPipeline.map (forced) / PodLanes.map",
                sequential_ms_per_pod=ms_seq / sets, forced_pipeline_ms_per_pod=ms_pipe / sets,
-               sequential_dof_per_s=N * n * sets / ms_seq * 1e3, recomputed=int(pipe.recomputed),
+               sequential_dof_per_s=N * n * sets / ms_seq * 1e3, lanes_ms_per_pod=ms_lanes / sets,
+               lanes_dof_per_s=N * n * sets / ms_lanes * 1e3, lanes_recomputed=int(lanes.recomputed),
+               subspace_dist_lanes_vs_sequential=worst_l, recomputed=int(pipe.recomputed),
                subspace_dist_pipeline_vs_sequential=worst)
     pipeline.shutdown()
     return res
