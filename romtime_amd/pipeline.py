@@ -318,9 +318,9 @@ class PodLanes:
     A small set's time is its n x n eigensolve - 32 workgroups on ONE XCD handing columns to each other - while the
     other seven XCDs idle.  A lane is a Context whose eigensolver works on XCD ``lane`` (option "eig_xcd") plus a
     stream of its own; set i runs its whole chain (Gram, scaling, eigenvalues, vectors, back-projection) on lane
-    i mod 8, so eight chains are on the chip together and no two eigensolver teams ever want the same CUs.  The `num`
-    rule only, as in PodPipeline (everything is enqueued ahead of the spectrum); a set whose spectrum turns out to
-    need deflated levels or a Rayleigh-Ritz step is recomputed by ``pod.pod_device``.  Single GPU.
+    i mod 8, so eight chains are on the chip together and no two eigensolver teams ever want the same CUs.
+    Everything is enqueued ahead of the spectrum (see run() for how `tol` is served); a set whose spectrum turns out
+    to need deflated levels or a Rayleigh-Ritz step is recomputed by ``pod.pod_device``.  Single GPU.
     """
 
     def __init__(self, lanes: int = 8, device=None):
@@ -352,10 +352,13 @@ class PodLanes:
             item["done"] = torch.cuda.Event()
             item["done"].record()
 
+    def _regular(self, item):
+        self.recomputed += 1
+        return pod.pod_device(item["X"], num=item["num"], tol=item["tol"], normalize=item["normalize"])
+
     def _finish(self, item):
         if item["direct"]:
-            self.recomputed += 1
-            return pod.pod_device(item["X"], num=item["num"], normalize=item["normalize"])
+            return self._regular(item)
         item["done"].synchronize()
         n, k = item["X"].shape[1], item["k"]
         head = item["head"].numpy()
@@ -363,21 +366,24 @@ class PodLanes:
         if item["normalize"] and zero_norm:
             raise ValueError("array must not contain infs or NaNs (zero-norm snapshot with normalize=True)")
         s = np.sqrt(np.clip(lam, 0.0, None))
-        gaps = lam[:k] - lam[1:k + 1] if k < n else np.r_[lam[:k - 1] - lam[1:k], lam[k - 1]]
-        ok = (status == 0 and s[0] > 0 and s[k - 1] >= pod.TWO_PASS_RATIO * s[0]
-              and gaps.min() >= pod.RR_GAP * max(lam[0], 1e-300) and item["X"].shape[0] >= n)
-        if not ok:
-            self.recomputed += 1
-            return pod.pod_device(item["X"], num=item["num"], normalize=item["normalize"])
+        energy = pod._energy(s)
+        r = pod.truncation_rank(s, energy, num=item["num"], tol=item["tol"])     # orth's own rule, after the fact
+        if status != 0 or not (1 <= r <= k) or not s[0] > 0 or item["X"].shape[0] < n:
+            return self._regular(item)
+        gaps = lam[:r] - lam[1:r + 1] if r < n else np.r_[lam[:r - 1] - lam[1:r], lam[r - 1]]
+        if s[r - 1] < pod.TWO_PASS_RATIO * s[0] or gaps.min() < pod.RR_GAP * max(lam[0], 1e-300):
+            return self._regular(item)           # deep or clustered among the kept modes: deflated levels / Rayleigh-Ritz
+        Q = item["Q"] if r == k else item["Q"][:, :r]
         for t in (item["Q"], item["colnorm"]):                      # allocated under the lane's stream, used by the caller's
             t.record_stream(torch.cuda.current_stream(self.device))
-        return dict(Q=item["Q"], s=s, energy=pod._energy(s), VT=None, r=k, passes=1, colnorm=item["colnorm"])
+        return dict(Q=Q, s=s, energy=energy, VT=None, r=r, passes=1, colnorm=item["colnorm"])
 
-    def run(self, snapshot_sets, num, normalize=True):
-        """Generator over the results (dicts as ``pod.pod_device`` returns) of ``orth(X, num=num, normalize=normalize)``
-        for every X of ``snapshot_sets`` (float64 CUDA tensors, N x n), in order; one set per lane is in flight."""
-        if not num:
-            raise ValueError("PodLanes enqueues ahead of the spectrum: it needs `num` (pod.py:51-53)")
+    def run(self, snapshot_sets, num=None, normalize=True, tol=None, cap=64):
+        """Generator over the results (dicts as ``pod.pod_device`` returns) of ``orth(X, num=num, tol=tol,
+        normalize=normalize)`` for every X of ``snapshot_sets`` (float64 CUDA tensors, N x n), in order; one set per lane
+        is in flight.  Everything is enqueued ahead of the spectrum: with ``num`` alone that many modes are computed;
+        with ``tol`` (or neither: the 1e-7 rule) ``cap`` modes are, orth's truncation rule is applied to the spectrum
+        afterwards and the basis cut to it - a set that wants more than ``cap`` modes takes the regular route."""
         main = torch.cuda.current_stream(self.device)
         ready = torch.cuda.Event()
         ready.record(main)                       # the snapshot sets were produced on the caller's stream
@@ -396,7 +402,8 @@ class PodLanes:
             if X.dim() != 2 or not X.is_cuda or X.dtype != torch.float64:
                 raise _lib.RomtimeHipError("PodLanes takes 2-D float64 CUDA tensors")
             n = X.shape[1]
-            item = dict(X=X, num=num, k=int(min(num, n)), normalize=bool(normalize), direct=not (3 <= n <= 512))
+            k = int(min(num, n)) if (num and not tol) else int(min(cap, n))
+            item = dict(X=X, num=num, tol=tol, k=k, normalize=bool(normalize), direct=not (3 <= n <= 512))
             if not item["direct"]:
                 self._enqueue(item, admitted % len(self.streams))
             admitted += 1
@@ -415,5 +422,5 @@ class PodLanes:
             done.record(st)
             main.wait_event(done)
 
-    def map(self, snapshot_sets, num, normalize=True):
-        return list(self.run(snapshot_sets, num, normalize=normalize))
+    def map(self, snapshot_sets, num=None, normalize=True, tol=None, cap=64):
+        return list(self.run(snapshot_sets, num=num, normalize=normalize, tol=tol, cap=cap))

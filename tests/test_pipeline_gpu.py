@@ -92,8 +92,18 @@ def test_lanes_match_single_pods_and_oracle():
         assert np.abs(Q.T @ Q - np.eye(k)).max() < 1e-10
         _same_columns(Q, single["Q"].cpu().numpy(), 1e-11)
         _same_columns(Q, Qo, 1e-9)
-    with pytest.raises(ValueError):
-        lanes.map(dev[:1], num=None)
+    # energy truncation (what the tree walks ask for, rom.py:165-183): `cap` modes are computed ahead of the spectrum and
+    # orth's rule cuts them afterwards; a set that wants more than `cap` takes the regular route
+    before = lanes.recomputed
+    tol = 1.0 - 1e-3
+    outs_t = lanes.map(dev[:10], tol=tol, normalize=False, cap=8)
+    for X, out in zip(mats[:10], outs_t):
+        Qo, so, eo = oracle.orth(X, tol=tol, normalize=False)
+        assert out["r"] == Qo.shape[1] and out["Q"].shape[1] == Qo.shape[1], (out["r"], Qo.shape)
+        np.testing.assert_allclose(out["energy"], eo, rtol=1e-10)
+        if Qo.shape[1]:
+            _same_columns(out["Q"].cpu().numpy(), Qo, 1e-9)
+    assert lanes.recomputed - before >= 1          # mats[7] is deep
     Z = ops.to_device(np.c_[mats[0][:, :5], np.zeros((mats[0].shape[0], 1))])
     with pytest.raises(ValueError):                                   # zero-norm column + normalize, as orth does
         lanes.map([Z], num=3, normalize=True)
