@@ -289,10 +289,19 @@ int rt_gram128(rt_ctx* ctx, const double* X, int64_t ks, int64_t ms, int64_t K, 
   p.flags = env_flags;
   p.counters = ctx->dev_counters;
 
-  const int S_off = n_off ? slots_max / n_off : 0;   // sub-splits per off-diagonal tile per XCD
-  // too little work per workgroup: slab traffic and two launches would dominate
-  if (p.kx / KB < 48L * (S_off ? S_off : slots_max / tiles1)) return RT_ERR_UNSUPPORTED;
-  const int S_diag = slots_max / tiles1;             // ... per diagonal tile
+  int S_off = n_off ? slots_max / n_off : 0;   // sub-splits per off-diagonal tile per XCD
+  int S_diag = slots_max / tiles1;             // ... per diagonal tile
+  // Shorter snapshot sets get fewer sub-splits, at least 48 stages each (below that the slab traffic and the two
+  // launches dominate), as long as an XCD still has 16 workgroups of the bigger launch to run: 1e5 x 256 then takes
+  // 197 us instead of the generic symmetric GEMM's 255, 2e5 x 128 93 instead of 286, 5e4 x 512 296 instead of 374;
+  // 3e4 x 384 (12 workgroups per XCD) is left to the generic kernel, which is faster there (188 vs 212 us).
+  {
+    const int cap = (int)(p.kx / KB / 48);
+    if (S_off > cap) S_off = cap;
+    if (S_diag > cap) S_diag = cap;
+    const int busiest = n_off ? n_off * S_off : tiles1 * S_diag;
+    if (cap < 1 || busiest < 16) return RT_ERR_UNSUPPORTED;
+  }
   const int nslots_off = S_off * n_off, nslots_diag = S_diag * tiles1;
   const size_t tile_bytes = sizeof(double) * BT * BT;
   void* slab = nullptr;
