@@ -58,7 +58,7 @@ constexpr int WROWS = 48;     // V rows kept in LDS per stage (banded FE operato
 constexpr int EMAX = PT;      // entries of one stage staged through LDS (one per thread)
 
 // == 16 (mod 32) doubles: conflict-free ds_read_b64 of the MFMA operands (16 tr already is for odd tr)
-__host__ __device__ constexpr bool separate_a(int tr) { return tr <= 4; }   // see project_wave
+__host__ __device__ constexpr bool separate_a(int tr) { return tr <= 5; }   // see project_wave
 __host__ __device__ constexpr int stride_of(int tr) { return 16 * tr + ((tr & 1) ? 0 : 16); }
 
 // Everything a stage needs to start its loads, in one wave-uniform 16-byte record (one scalar load, issued a
@@ -173,9 +173,10 @@ __device__ __forceinline__ void project_wave(const ProjParams& p, const StageRec
   constexpr int U = TR <= 2 ? 6 : (TR <= 4 ? 3 : 2);          // entries per gather chunk (2 U TR transient VGPRs)
   static_assert(U <= EPAD, "a chunk may overrun the staged entries by U - 1");
   double* sW = sm;                                            // [WROWS][STRIDE]  window of V rows
-  // r <= 64: the stage's own rows are copied to sA, so that the next window can be committed while the MFMAs run -
-  // two barriers per stage instead of three (r = 64: 0.69 -> 0.64 ms per 32 vectors, r = 40: 0.52 -> 0.49).  At
-  // r = 80 the copy's registers spill and the kernel loses 3 %: there the A operand is read out of the window.
+  // r <= 80: the stage's own rows are copied to sA, so that the next window can be committed while the MFMAs run -
+  // two barriers per stage instead of three (r = 64: 0.69 -> 0.63 ms per 32 vectors, r = 40: 0.52 -> 0.49, r = 80 with
+  // 120 vectors: 3.12 -> 3.01 ms; at r = 80 the copy goes one pair at a time, its registers would spill otherwise).
+  // Beyond, one workgroup per CU anyway and the A operand is read out of the window.
   constexpr bool SEP_A = separate_a(TR);
   double* sA = sm + WROWS * STRIDE;                           // [PK][STRIDE]     the stage's own V rows (SEP_A)
   double* sB = sA + (SEP_A ? PK * STRIDE : 0);                // [PK][STRIDE]     rows of A_b V (B operand)
@@ -306,13 +307,23 @@ __device__ __forceinline__ void project_wave(const ProjParams& p, const StageRec
       if (RPP * PAIRS == PT || wrow < RPP) {
         const double* src = w_lds + (k0 - c_lo) * STRIDE;
         double* dst = sA + (w_lds - sW);
-        d2 t[NAP];
+        if constexpr (TR <= 4) {
+          d2 t[NAP];
 #pragma unroll
-        for (int q = 0; q < NAP; ++q)
-          if (RPP * (q + 1) <= PK || wrow < PK - RPP * q) t[q] = *reinterpret_cast<const d2*>(src + q * RPP * STRIDE);
+          for (int q = 0; q < NAP; ++q)
+            if (RPP * (q + 1) <= PK || wrow < PK - RPP * q) t[q] = *reinterpret_cast<const d2*>(src + q * RPP * STRIDE);
 #pragma unroll
-        for (int q = 0; q < NAP; ++q)
-          if (RPP * (q + 1) <= PK || wrow < PK - RPP * q) *reinterpret_cast<d2*>(dst + q * RPP * STRIDE) = t[q];
+          for (int q = 0; q < NAP; ++q)
+            if (RPP * (q + 1) <= PK || wrow < PK - RPP * q) *reinterpret_cast<d2*>(dst + q * RPP * STRIDE) = t[q];
+        } else {   // registers are scarce: one pair at a time
+#pragma unroll
+          for (int q = 0; q < NAP; ++q)
+            if (RPP * (q + 1) <= PK || wrow < PK - RPP * q) {
+              const d2 t = *reinterpret_cast<const d2*>(src + q * RPP * STRIDE);
+              __builtin_amdgcn_sched_barrier(0);
+              *reinterpret_cast<d2*>(dst + q * RPP * STRIDE) = t;
+            }
+        }
       }
     }
     // B operand: rows of A_b V.  The entries of a row are taken U at a time: U entry reads, then their U TR
