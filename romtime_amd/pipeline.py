@@ -353,7 +353,13 @@ class PodLanes:
             item["done"].record()
 
     def _regular(self, item):
+        """The set on the caller's context and stream.  Its eigensolver team goes to the XCD of THAT context (0 unless
+        set otherwise), where a lane may have a team in flight: two teams that each want every CU of one XCD can
+        starve each other into the hand-off's time-out, so that lane is drained first."""
         self.recomputed += 1
+        xcd = int(_lib.Context.current().options.get("eig_xcd", 0))
+        if xcd < len(self.streams):
+            self.streams[xcd].synchronize()
         return pod.pod_device(item["X"], num=item["num"], tol=item["tol"], normalize=item["normalize"])
 
     def _finish(self, item):
