@@ -320,7 +320,9 @@ class PodLanes:
     stream of its own; set i runs its whole chain (Gram, scaling, eigenvalues, vectors, back-projection) on lane
     i mod 8, so eight chains are on the chip together and no two eigensolver teams ever want the same CUs.
     Everything is enqueued ahead of the spectrum (see run() for how `tol` is served); a set whose spectrum turns out
-    to need deflated levels or a Rayleigh-Ritz step is recomputed by ``pod.pod_device``.  Single GPU.
+    to need deflated levels or a Rayleigh-Ritz step is recomputed by ``pod.pod_device``.  Single GPU.  While a ``run()``
+    generator is open, PODs of OTHER contexts on the same device may meet a lane's team on their XCD (``map()`` has no
+    such window).
     """
 
     def __init__(self, lanes: int = 8, device=None):
