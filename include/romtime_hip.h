@@ -115,7 +115,8 @@ int rt_pod_orth(rt_ctx* ctx, const double* X, int64_t n_rows, int64_t n_cols, in
  * leading eigenvectors, back-projection Q (n_rows x k, row-major) = X D^-1 W S^-1.  The decisions `orth` takes from the
  * spectrum (deflated levels for deep spectra, Rayleigh-Ritz for clusters, the zero-norm error) are the caller's, after
  * the fact: lam (n_cols, descending, device), status2 (device ints: [0] eigensolver hand-off status, [1] zero-norm
- * flag), colnorm (n_cols).  G (n x n), Z and Zs (n x k) are work space the caller owns.  One host call per snapshot set:
+ * flag), colnorm (n_cols).  G (n x n), Z and Zs (n x k) are work space the caller owns; 3 <= n_cols <= 1024, k <= n_cols.
+ * One host call per snapshot set:
  * what lets romtime_amd.pipeline.PodLanes keep eight small PODs on the chip (eight contexts, "eig_xcd" 0 .. 7). */
 int rt_pod_enqueue(rt_ctx* ctx, const double* X, int64_t n_rows, int64_t n_cols, int64_t ld, int layout, int64_t k,
                    int normalize, double* G, double* colnorm, double* lam, int* status2, double* Z, double* Zs, double* Q);
