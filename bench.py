@@ -11,6 +11,10 @@ same for N = 1, 2, 4, 8) and the Gram matrix is all-reduced over RCCL.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N ...      (no launcher: the script starts its N ranks itself, before any GPU call)
+
+A line is only ever printed with n_gpus == --gpus; every line carries `fallback_counters` (eigensolver hand-off
+time-outs, contexts that left the one-XCD hand-off form, sets recomputed on the regular route, summed over the ranks).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with `roofline` for the dominant
 kernel (the Gram MFMA kernel, timed with HIP events on its own stream inside the timed region)
@@ -193,6 +197,105 @@ def secondary_online_sweep(ctx, device, nt, n_mu, r, n_h, with_cpu):
     return out
 
 
+def free_port():
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def self_launch(n_ranks):
+    """Start `n_ranks` copies of this script (one per GPU: RANK = LOCAL_RANK = i, rendezvous on 127.0.0.1) and wait for
+    them; returns the exit code.  Called BEFORE anything initialises the GPU in this process - a process that has must
+    neither exec nor be forked from.  A rank that dies takes the others with it (by PID, never by pattern)."""
+    import signal
+    import subprocess
+
+    have = torch.cuda.device_count()          # counting devices does not initialise the runtime
+    backend = os.environ.get("ROMTIME_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and not os.environ.get("ROMTIME_BENCH_DRYRUN") and have < n_ranks:
+        print(f"bench.py: --gpus {n_ranks} but {have} GPU(s) visible (RCCL needs one GPU per rank; "
+              f"ROMTIME_BENCH_BACKEND=gloo rehearses with shared GPUs)", file=sys.stderr)
+        return 2
+    port = os.environ.get("MASTER_PORT") or str(free_port())
+    procs = []
+    for i in range(n_ranks):
+        env = dict(os.environ, RANK=str(i), LOCAL_RANK=str(i), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    alive = set(range(n_ranks))
+    while alive:
+        for i in sorted(alive):
+            code = procs[i].poll()
+            if code is None:
+                continue
+            alive.discard(i)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 128 - code
+                print(f"bench.py: rank {i} exited with {code}; stopping the other ranks", file=sys.stderr)
+                for j in alive:
+                    procs[j].send_signal(signal.SIGTERM)
+        if alive:
+            time.sleep(0.05)
+    return rc
+
+
+def dry_run_line(args, world, rank):
+    """ROMTIME_BENCH_DRYRUN=1: the launch path, the rendezvous, the shard arithmetic and the shape of the line WITHOUT
+    any computation - no GPU is touched, `value` is null and the line says so.  What tests/test_bench_launch_cpu.py
+    runs; never a measurement."""
+    import torch.distributed as dist
+
+    group_world = world
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    n_chunks = (args.rows + CHUNK_ROWS - 1) // CHUNK_ROWS
+    per_rank = (n_chunks + world - 1) // world
+    n_local = sum(min(CHUNK_ROWS, args.rows - c * CHUNK_ROWS)
+                  for c in range(rank * per_rank, min(n_chunks, (rank + 1) * per_rank)))
+    rows = torch.tensor([float(n_local)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(rows)
+        group_world = dist.get_world_size()
+    if rank == 0:
+        assert int(rows.item()) == args.rows, "the row shards do not add up to the global matrix"
+        line = base_line(args, group_world, n_local, value=None, ms_per_step=None, passes=None, mode="dry-run",
+                         latency_ms=None)
+        line["dry_run"] = True
+        line["fallback_counters"] = dict.fromkeys(FALLBACK_COUNTERS)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+FALLBACK_COUNTERS = ("eig_timeouts", "eig_general_form", "eig_one_xcd", "sets_recomputed")
+
+
+def base_line(args, world, n_local, value, ms_per_step, passes, mode, latency_ms):
+    n_h, n, r = args.rows, args.cols, args.modes
+    return {
+        "metric": "snapshot-DoF/s for POD build",
+        "value": value,
+        "unit": "snapshot-DoF/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"pod_{n_h}x{n}_r{r}_normalize", "n_h": n_h, "n_snapshots": n, "modes": r,
+                   "rows_per_gpu": n_local, "passes": passes, "parallelism": f"row-sharded x{world}",
+                   "mode": mode, "single_pod_latency_ms": latency_ms},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -213,9 +316,21 @@ def main():
                          "CU-partitioned streams); latency: one pod_device call after the other; auto = pipeline")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: start the N ranks ourselves.  This process has not touched the
+        # GPU (importing torch does not) and never will: it only waits for its children.
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        # a line whose n_gpus differs from what was asked for would be read as the N-GPU number
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to run")
+    dry_run = bool(os.environ.get("ROMTIME_BENCH_DRYRUN"))
+    if dry_run:
+        return dry_run_line(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: romtime_amd has no CPU path")
     # ROMTIME_BENCH_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks then share
@@ -302,6 +417,7 @@ def main():
             latency_ms = 1e3 * (time.perf_counter() - t1) / 5
         del outs
         pipe.close()
+        counts = [pipe.ctxE.counter(c) + ctx.counter(c) for c in FALLBACK_COUNTERS[:3]] + [pipe.recomputed]
         del pipe
         from romtime_amd import pipeline as _pipeline
 
@@ -326,13 +442,19 @@ def main():
         elapsed = time.perf_counter() - t0
         ctx.set_profile(False)
         stage_ms = dict(pod.stage_timings())   # stream events of the last step, resolved after the timed region
+        counts = [ctx.counter(c) for c in FALLBACK_COUNTERS[:3]] + [0]
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    # what would hide a slow step: eigensolver hand-off time-outs, contexts that fell back to the general hand-off form,
+    # sets recomputed on the regular route - summed over the ranks (warm-up included) and printed in every line
+    fb = torch.tensor(counts, dtype=torch.float64, device=device)
     if world > 1:
         import torch.distributed as dist
 
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.all_reduce(fb, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
+    fallback = {name: int(v) for name, v in zip(FALLBACK_COUNTERS, fb.tolist())}
 
     if rank == 0:
         pipe_mode = mode == "pipeline"
@@ -361,25 +483,10 @@ def main():
                         algorithmic_flops=alg_flops, algorithmic_bytes=alg_bytes,
                         hbm_frac=alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         note="FP64 Gram at n=512 is 64 flop/B: matrix-core bound, not HBM bound")
-        line = {
-            "metric": "snapshot-DoF/s for POD build",
-            "value": value,
-            "unit": "snapshot-DoF/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": ms_per_step,
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
-            "config": {"workload": f"pod_{n_h}x{n}_r{r}_normalize", "n_h": n_h, "n_snapshots": n, "modes": r,
-                       "rows_per_gpu": n_local, "passes": out["passes"], "parallelism": f"row-sharded x{world}",
-                       "mode": mode, "single_pod_latency_ms": latency_ms},
-            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
-            "roofline": roofline,
-        }
+        line = base_line(args, world, n_local, value, ms_per_step, out["passes"], mode, latency_ms)
+        line["stage_ms"] = {k: round(v, 4) for k, v in stage_ms.items()}
+        line["roofline"] = roofline
+        line["fallback_counters"] = fallback
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(n, r, min(args.cpu_sample_rows, n_h))
         if world == 1 and not args.no_secondary:
