@@ -83,7 +83,9 @@ constexpr int PIV_THREADS = 1024;          // the once-per-block serial kernel
 
 struct StepState {   // what a step leaves behind, all in device memory
   int m, nparts;
-  double* pv1;   // per-workgroup (top1, index, top2) of the newest residual column
+  // per-workgroup (top1, index, top2) of a residual column, TWO sets: column k's launch writes set k & 1 while all of
+  // its workgroups - whenever they are scheduled - still read set (k - 1) & 1 to finish the step before
+  double* pv1;
   long* pi1;
   double* pv2;
   long* idx;
@@ -111,9 +113,13 @@ struct StepShared {
 // column k of R holds t_k, already reduced by the columns before the block.  Everything here is at most BLK x BLK:
 // the part of row kp of L^-1 that lies before the block is not needed until the next block starts
 // (deim_block_start_kernel).  `persist`: this caller writes idx, delta, margin and the row's corner to memory.
+// Nothing read here is written by the launch that calls it: the partials come from the other parity set, t_k from
+// the block's t columns `Tb` (written by phase A only), residual columns kp and earlier from finished launches - so
+// it does not matter when a workgroup runs relative to the others of its launch (N beyond one round of resident
+// workgroups, other streams sharing the chip).
 template <int T>
-__device__ __forceinline__ void deim_finish_step(const double* R, long ldr, int kp, int jstart, bool want_yt,
-                                                 bool persist, const StepState& a, StepShared& sh) {
+__device__ __forceinline__ void deim_finish_step(const double* R, const double* Tb, long ldr, int kp, int jstart,
+                                                 bool want_yt, bool persist, const StepState& a, StepShared& sh) {
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int m = a.m, n = kp - jstart;   // earlier columns of the block
   // corner of L^-1, deltas and indices of the block's earlier columns: independent of the new pivot
@@ -126,7 +132,10 @@ __device__ __forceinline__ void deim_finish_step(const double* R, long ldr, int 
     sh.pidx[tid] = a.idx[jstart + tid];
   }
   Top2 best{-1.0, 0x7fffffffffffffffL, -1.0};
-  for (int q = tid; q < a.nparts; q += T) best = top2_merge(best, Top2{a.pv1[q], a.pi1[q], a.pv2[q]});
+  {
+    const long set = (long)(kp & 1) * a.nparts;
+    for (int q = tid; q < a.nparts; q += T) best = top2_merge(best, Top2{a.pv1[set + q], a.pi1[set + q], a.pv2[set + q]});
+  }
   best = top2_wave(best);
   if (lane == 0) sh.red[wid] = best;
   __syncthreads();
@@ -144,9 +153,9 @@ __device__ __forceinline__ void deim_finish_step(const double* R, long ldr, int 
     sh.del[n] = R[(long)kp * ldr + p];
     sh.pidx[n] = p;
   }
-  if (want_yt && tid >= 64 && tid - 64 <= n) {   // t_k at the block's pivot rows
-    const int j = tid - 64;
-    sh.b[j] = R[(long)(kp + 1) * ldr + (j < n ? sh.pidx[j] : p)];
+  if (want_yt && tid >= 64 && tid - 64 <= n) {   // t_k at the block's pivot rows: from the block's t columns, which
+    const int j = tid - 64;                       // no column launch writes (column k of R is being overwritten by r_k)
+    sh.b[j] = Tb[(long)(kp + 1 - jstart) * ldr + (j < n ? sh.pidx[j] : p)];
   }
   __syncthreads();
   // row kp of the corner:  Linv[kp][j] = -sum_{i=j}^{kp-1} l_i Linv[i][j],  Linv[kp][kp] = 1
@@ -175,9 +184,10 @@ __device__ __forceinline__ void deim_finish_step(const double* R, long ldr, int 
 // Column k of a block: first every workgroup finishes step k - 1 for itself (deim_finish_step: the numbers are
 // small and all in the L2; doing it here instead of in a single-workgroup kernel between two chip-wide ones takes
 // the 9 us "pivot" launch out of every step), then
-//   r_k = R[k] - sum_{jstart<=j<k} R[j] * yt[j]  (in place in column k)  and the per-workgroup top-2 of |r_k|.
-__global__ __launch_bounds__(RES_THREADS) void deim_column_kernel(double* R, long ldr, long N, int k, int jstart,
-                                                                  StepState st) {
+//   r_k = t_k - sum_{jstart<=j<k} R[j] * yt[j]  (t_k from the block's t columns, r_k into column k of R)  and the
+//   per-workgroup top-2 of |r_k|.
+__global__ __launch_bounds__(RES_THREADS) void deim_column_kernel(double* __restrict__ R, const double* __restrict__ Tb,
+                                                                  long ldr, long N, int k, int jstart, StepState st) {
   __shared__ StepShared sh;
   const int tid = threadIdx.x;
   const int nj = k - jstart;   // < BLK
@@ -195,10 +205,10 @@ __global__ __launch_bounds__(RES_THREADS) void deim_column_kernel(double* R, lon
 #pragma unroll
       for (int j = 0; j < BLK - 1; ++j)
         if (j < nj) av[h][j] = *reinterpret_cast<const d2*>(col + (long)j * ldr);
-      rv[h] = *reinterpret_cast<const d2*>(R + (long)k * ldr + row);
+      rv[h] = *reinterpret_cast<const d2*>(Tb + (long)nj * ldr + row);
     }
   }
-  if (nj > 0) deim_finish_step<RES_THREADS>(R, ldr, k - 1, jstart, true, blockIdx.x == 0, st, sh);
+  if (nj > 0) deim_finish_step<RES_THREADS>(R, Tb, ldr, k - 1, jstart, true, blockIdx.x == 0, st, sh);
   Top2 best{-1.0, 0x7fffffffffffffffL, -1.0};
 #pragma unroll
   for (int h = 0; h < H; ++h) {
@@ -228,9 +238,10 @@ __global__ __launch_bounds__(RES_THREADS) void deim_column_kernel(double* R, lon
   if (tid == 0) {
     Top2 t = sh.red[0];
     for (int w = 1; w < RES_THREADS / 64; ++w) t = top2_merge(t, sh.red[w]);
-    st.pv1[blockIdx.x] = t.v1;
-    st.pi1[blockIdx.x] = t.i1;
-    st.pv2[blockIdx.x] = t.v2;
+    const long slot = (long)(k & 1) * st.nparts + blockIdx.x;
+    st.pv1[slot] = t.v1;
+    st.pi1[slot] = t.i1;
+    st.pv2[slot] = t.v2;
   }
 }
 
@@ -250,7 +261,7 @@ __global__ __launch_bounds__(PIV_THREADS) void deim_block_start_kernel(const dou
   __shared__ double s_l22[BLK][BLK];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int m = st.m, np = k0 - kb;
-  deim_finish_step<PIV_THREADS>(R, ldr, k0 - 1, kb, false, true, st, sh);
+  deim_finish_step<PIV_THREADS>(R, nullptr, ldr, k0 - 1, kb, false, true, st, sh);
   __threadfence_block();
   __syncthreads();
   if (kb > 0 && k0 < m) {   // (after the last block nobody reads L^-1 again)
@@ -332,9 +343,12 @@ __global__ __launch_bounds__(PIV_THREADS) void deim_block_start_kernel(const dou
 }
 
 // t_c = phi_c - sum_{j<k0} R_j YT[c][j] for the nb columns of the block in ONE sweep over R[:, :k0]:
-// the k0 residual columns are read once per block instead of once per column.
-__global__ __launch_bounds__(RES_THREADS) void deim_phase_a_kernel(double* __restrict__ R, long ldr, long N, int k0,
-                                                                   int nb, int m, const double* __restrict__ YT) {
+// the k0 residual columns are read once per block instead of once per column.  The t columns go to the block's own
+// buffer Tb (column-major, ldr): the column launches read them there and write the residuals into R, so no launch
+// reads what it writes.  k0 = 0: a copy of the first block's columns.
+__global__ __launch_bounds__(RES_THREADS) void deim_phase_a_kernel(const double* __restrict__ R, double* __restrict__ Tb,
+                                                                   long ldr, long N, int k0, int nb, int m,
+                                                                   const double* __restrict__ YT) {
   extern __shared__ double s_yt[];  // [k0][BLK]
   const int tid = threadIdx.x;
   for (int q = tid; q < k0 * BLK; q += RES_THREADS) {
@@ -361,11 +375,10 @@ __global__ __launch_bounds__(RES_THREADS) void deim_phase_a_kernel(double* __res
 #pragma unroll
   for (int c = 0; c < BLK; ++c) {
     if (c < nb) {
-      d2* dst = reinterpret_cast<d2*>(R + (long)(k0 + c) * ldr + row);
-      d2 r = *dst;
+      d2 r = *reinterpret_cast<const d2*>(R + (long)(k0 + c) * ldr + row);
       r.x -= acc[c].x;
       r.y -= acc[c].y;
-      *dst = r;
+      *reinterpret_cast<d2*>(Tb + (long)c * ldr + row) = r;
     }
   }
 }
@@ -417,21 +430,23 @@ extern "C" int rt_deim_greedy(rt_ctx* ctx, const double* Phi, int64_t N, int64_t
   const long ldr = (N + 15) / 16 * 16;
   const int nparts = (int)((N + RES_ROWS - 1) / RES_ROWS);   // workgroups of the block sweeps
   const int ncol = (int)((N + COL_ROWS - 1) / COL_ROWS);     // workgroups (= argmax partials) of a column's kernel
-  // scratch: R | Linv | delta | YT | pv1 | pv2 | pi1
+  // scratch: R | Tb | Linv | delta | YT | pv1 | pv2 | pi1  (the three partial arrays twice: one set per column parity)
   size_t off = 0;
   auto take = [&off](size_t bytes) {
     size_t o = off;
     off += (bytes + 255) / 256 * 256;
     return o;
   };
-  const size_t oR = take(sizeof(double) * ldr * m), oL = take(sizeof(double) * m * m), oD = take(sizeof(double) * m),
-               oYT = take(sizeof(double) * BLK * m), oV1 = take(sizeof(double) * ncol),
-               oV2 = take(sizeof(double) * ncol), oI1 = take(sizeof(long) * ncol);
+  const size_t oR = take(sizeof(double) * ldr * m), oT = take(sizeof(double) * ldr * BLK),
+               oL = take(sizeof(double) * m * m), oD = take(sizeof(double) * m), oYT = take(sizeof(double) * BLK * m),
+               oV1 = take(sizeof(double) * 2 * ncol), oV2 = take(sizeof(double) * 2 * ncol),
+               oI1 = take(sizeof(long) * 2 * ncol);
   void* base = nullptr;
   int rc = rt_scratch2(ctx, off, &base);
   if (rc != RT_OK) return rc;
   char* b8 = static_cast<char*>(base);
   double* R = reinterpret_cast<double*>(b8 + oR);
+  double* Tb = reinterpret_cast<double*>(b8 + oT);
   double* Linv = reinterpret_cast<double*>(b8 + oL);
   double* delta = reinterpret_cast<double*>(b8 + oD);
   double* YT = reinterpret_cast<double*>(b8 + oYT);
@@ -456,13 +471,12 @@ extern "C" int rt_deim_greedy(rt_ctx* ctx, const double* Phi, int64_t N, int64_t
   RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&deim_phase_a_kernel), 1024 * BLK * 8));
   for (int k0 = 0; k0 < (int)m; k0 += BLK) {
     const int nb = ((int)m - k0 < BLK) ? (int)m - k0 : BLK;
-    if (k0 > 0) {
+    if (k0 > 0)
       hipLaunchKernelGGL(deim_block_start_kernel, dim3(1), dim3(PIV_THREADS), 0, st, R, ldr, k0, k0 - BLK, nb, state, YT);
-      hipLaunchKernelGGL(deim_phase_a_kernel, dim3(nparts), dim3(RES_THREADS), sizeof(double) * k0 * BLK, st, R, ldr,
-                         (long)N, k0, nb, (int)m, YT);
-    }
+    hipLaunchKernelGGL(deim_phase_a_kernel, dim3(nparts), dim3(RES_THREADS), sizeof(double) * k0 * BLK, st, R, Tb, ldr,
+                       (long)N, k0, nb, (int)m, YT);
     for (int k = k0; k < k0 + nb; ++k)
-      hipLaunchKernelGGL(deim_column_kernel, dim3(ncol), dim3(RES_THREADS), 0, st, R, ldr, (long)N, k, k0, state);
+      hipLaunchKernelGGL(deim_column_kernel, dim3(ncol), dim3(RES_THREADS), 0, st, R, Tb, ldr, (long)N, k, k0, state);
   }
   {  // the last step
     const int kb = ((int)m - 1) / BLK * BLK;

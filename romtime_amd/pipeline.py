@@ -28,6 +28,7 @@ from __future__ import annotations
 
 import collections
 import ctypes as C
+import weakref
 
 import numpy as np
 import torch
@@ -39,17 +40,24 @@ _p = C.c_void_p
 
 SMALL_SET = 150_000_000   # rows x columns below which a set takes the regular route (see run())
 _STREAMS: dict = {}
+_OPEN_RUNS = weakref.WeakSet()   # PodPipeline.run generators that have not finished (closed by shutdown())
 
 
 def shutdown():
-    """Destroy the process-wide masked streams.  Call it when every tensor produced by a pipeline has been released
-    (it synchronises, collects garbage and empties torch's cache first); registered with ``atexit`` as well, because a
-    process that ends with CU-masked queues alive was seen to crash in the profiler's finaliser (rocprofv3)."""
+    """Destroy the process-wide masked streams; registered with ``atexit`` as well, because a process that ends with
+    CU-masked queues alive was seen to crash in the profiler's finaliser (rocprofv3).  Safe whatever the caller still
+    holds: every tensor a pipeline hands out (Q, colnorm) is allocated on the CALLER's stream before the masked stream
+    is entered, so no block that outlives a pipeline call belongs to a masked stream's pool (torch's allocator tags a
+    block with the stream it was allocated under and must not meet a destroyed stream at teardown); what was allocated
+    under the masked streams are the pipeline's own work buffers, dropped when a set is handed out, and the open
+    generators that could still hold some are closed here first."""
     import gc
 
     if not _STREAMS:
         return
     try:
+        for gen in list(_OPEN_RUNS):
+            gen.close()                       # drops the in-flight items (work buffers allocated under masked streams)
         torch.cuda.synchronize()
         gc.collect()
         torch.cuda.empty_cache()
@@ -192,7 +200,7 @@ class PodPipeline:
                     item["payload"] = torch.empty(n * (k + 2) + 2, dtype=torch.float64, device=item["G"].device)
                 dist.broadcast(item["payload"], src=dist.get_global_rank(self.group_e, item["owner"]), group=self.group_e)
             payload = item["payload"]
-            item["colnorm"] = payload[n:2 * n]
+            item["colnorm"].copy_(payload[n:2 * n])                # handed out: lives on the caller's stream (admit())
             item["Zs"] = payload[2 * n + 2:].view(n, k)
             head = torch.cat([payload[:n], payload[2 * n:2 * n + 2], item["Gbuf"][-1:]])
             item["head"] = torch.empty(head.numel(), dtype=torch.float64).pin_memory()
@@ -206,14 +214,22 @@ class PodPipeline:
         ctx, st = self.ctxG, self.sG
         with ctx.use(st):
             st.wait_event(item["e"])
-            item["Q"] = ops.gemm_nn(item["X"], item["Zs"])
+            ops.gemm_nn(item["X"], item["Zs"], out=item["Q"])      # Q: allocated on the caller's stream by admit()
             item["b"] = torch.cuda.Event(enable_timing=True)
             item["b"].record()
 
+    def _regular(self, item):
+        """The set on the caller's context and (unmasked) stream.  Its eigensolver team wants every CU of one XCD,
+        stream E's CUs included, where teams of later sets may be spinning: two partly resident teams can starve each
+        other into the hand-off's time-out, so stream E is drained first (PodLanes._regular does the same for its
+        lane)."""
+        self.recomputed += 1
+        self.sE.synchronize()
+        return pod.pod_device(item["X"], num=item["num"], normalize=item["normalize"], group=self.group)
+
     def _finish(self, item):
         if item["direct"]:
-            self.recomputed += 1
-            return pod.pod_device(item["X"], num=item["num"], normalize=item["normalize"], group=self.group)
+            return self._regular(item)
         item["b"].synchronize()
         n, k = item["X"].shape[1], item["k"]
         head = item["head"].numpy()
@@ -232,24 +248,22 @@ class PodPipeline:
         self.gram_kernel_ms.append(self.last_stage_ms["gram_kernel_ms"])
         if not ok:
             # what pod_device decides after the fact too: this spectrum needs deflated levels / a Rayleigh-Ritz step
-            self.recomputed += 1
-            return pod.pod_device(item["X"], num=item["num"], normalize=item["normalize"], group=self.group)
-        item["Q"].record_stream(torch.cuda.current_stream(self.device))   # allocated under stream G, used by the caller's
+            return self._regular(item)
         return dict(Q=item["Q"], s=s, energy=energy, VT=None, r=k, passes=1, colnorm=item["colnorm"])
 
     # ---- driver -----------------------------------------------------------------------------------------------
     def run(self, snapshot_sets, num, normalize=True, depth=2):
         """Generator over the results (dicts as ``pod.pod_device`` returns) of ``orth(X, num=num, normalize=normalize)``
-        for every X of ``snapshot_sets`` (float64 CUDA tensors, N x n), in order.  ``depth`` sets are in flight."""
+        for every X of ``snapshot_sets`` (float64 CUDA tensors, N x n; any iterable, also a lazy one that produces each
+        set on the caller's stream when asked for it), in order.  ``depth`` sets are in flight."""
         if not num:
             raise ValueError("PodPipeline enqueues ahead of the spectrum: it needs `num` (pod.py:51-53)")
+        gen = self._run(snapshot_sets, num, normalize, depth)
+        _OPEN_RUNS.add(gen)
+        return gen
+
+    def _run(self, snapshot_sets, num, normalize, depth):
         main = torch.cuda.current_stream(self.device)
-        ready = torch.cuda.Event()
-        ready.record(main)                       # the snapshot sets were produced on the caller's stream
-        self.sG.wait_event(ready)
-        self.sE.wait_event(ready)
-        if self.sC is not None:
-            self.sC.wait_event(ready)
         flight = collections.deque()
         it = iter(snapshot_sets)
         self._admitted = 0
@@ -275,6 +289,16 @@ class PodPipeline:
             rows = X.shape[0] * self.world
             item["direct"] = not (3 <= n <= 512) or rows * n < self.small_set
             if not item["direct"]:
+                # This set may have been produced on the caller's stream a moment ago (next(it) of a lazy iterable):
+                # the pipeline's streams wait for THIS point of the caller's stream, per set.  What is handed out is
+                # allocated here, on the caller's stream (see shutdown()).
+                item["Q"] = torch.empty((X.shape[0], item["k"]), dtype=torch.float64, device=X.device)
+                item["colnorm"] = torch.empty(n, dtype=torch.float64, device=X.device)
+                ready = torch.cuda.Event()
+                ready.record(main)
+                for st in (self.sG, self.sE, self.sC):
+                    if st is not None:
+                        st.wait_event(ready)
                 self._gram(item)
                 self._eig(item)
             return item
@@ -393,10 +417,6 @@ class PodLanes:
         with ``tol`` (or neither: the 1e-7 rule) ``cap`` modes are, orth's truncation rule is applied to the spectrum
         afterwards and the basis cut to it - a set that wants more than ``cap`` modes takes the regular route."""
         main = torch.cuda.current_stream(self.device)
-        ready = torch.cuda.Event()
-        ready.record(main)                       # the snapshot sets were produced on the caller's stream
-        for st in self.streams:
-            st.wait_event(ready)
         it = iter(snapshot_sets)
         pending = collections.deque()
         admitted = 0
@@ -413,7 +433,11 @@ class PodLanes:
             k = int(min(num, n)) if (num and not tol) else int(min(cap, n))
             item = dict(X=X, num=num, tol=tol, k=k, normalize=bool(normalize), direct=not (3 <= n <= 512))
             if not item["direct"]:
-                self._enqueue(item, admitted % len(self.streams))
+                lane = admitted % len(self.streams)
+                ready = torch.cuda.Event()       # a lazy iterable produces this set on the caller's stream just now
+                ready.record(main)
+                self.streams[lane].wait_event(ready)
+                self._enqueue(item, lane)
             admitted += 1
             pending.append(item)
             return True

@@ -127,6 +127,31 @@ def test_greedy_random(ops, N, m):
     assert list(idx2.cpu().numpy()) == list(dofs)
 
 
+def test_greedy_more_workgroups_than_the_chip_holds(ops):
+    """N = 3e6: a column's kernel has 2930 workgroups, more than one round of resident ones (256 CUs x 8), so late
+    workgroups of a launch start after early ones have finished.  Every workgroup finishes the step before for itself
+    from what earlier LAUNCHES left (the other parity's partials, the block's t columns), never from what its own
+    launch writes - round 2's kernel read both (wrong pivots beyond ~1-2e6 rows).  Also a second stream
+    keeps the chip busy meanwhile, which perturbs the order workgroups are dispatched in."""
+    N, m = 3_000_000, 16
+    rng = np.random.RandomState(16)
+    B = rng.standard_normal((N, m)) / np.sqrt(N)
+    B[:, 1:] += 0.3 * B[:, :1]          # correlated columns: the residuals differ from the columns themselves
+    dofs, PT_U, margin = oracle.deim_greedy(B)
+    assert margin.min() > 1e-6          # no near-tie that rounding could legitimately resolve differently
+    Bd = ops.to_device(np.asfortranarray(B))
+    side = torch.cuda.Stream()
+    filler = torch.randn(4096, 4096, device="cuda")
+    for trial in range(3):
+        with torch.cuda.stream(side):
+            for _ in range(20):
+                filler @ filler
+        idx, PT_U_d, _ = ops.deim_greedy(Bd)
+        assert list(idx.cpu().numpy()) == list(dofs), trial
+        np.testing.assert_array_equal(PT_U_d.cpu().numpy(), PT_U)
+    torch.cuda.synchronize()
+
+
 def _penta(N, rng):
     offs = [-2, -1, 0, 1, 2]
     rows, cols = [], []

@@ -181,3 +181,66 @@ def test_row_sharded_pipeline_two_ranks_one_gpu():
         np.testing.assert_allclose(ret[0][j]["s"][:k], single["s"][:k], rtol=1e-11)
         Q = np.concatenate([ret[r][j]["Q"] for r in range(world)], axis=0)      # row slabs stack back into the basis
         _same_columns(Q, Qs, 1e-10)
+
+
+def test_lazy_snapshot_sets_are_ordered_after_their_producer():
+    """A lazy iterable produces each snapshot set on the caller's stream when the pipeline asks for it (the tree-walk
+    use: one set per parameter).  The pipeline's streams must wait for THAT point of the caller's stream, per set
+    (the `ready` event used to be recorded once, before any set was pulled).  The producer here is slow on
+    purpose - a long chain of kernels that fills the buffer last - so a Gram that does not wait sees the wrong data."""
+    from romtime_amd import ops, pod
+    from romtime_amd.pipeline import PodLanes, PodPipeline
+
+    rng = np.random.RandomState(11)
+    k = 5
+    host = [_matrix(rng, 6000, 64, 1.0 + 0.2 * i) for i in range(5)]
+    final = [ops.to_device(m) for m in host]
+    burn = torch.randn(2048, 2048, device="cuda")
+
+    def lazy():
+        for Xf in final:
+            X = torch.zeros_like(Xf)           # what a Gram that runs too early would read
+            for _ in range(30):
+                burn @ burn                    # ~ms of work on the caller's stream before the set exists
+            X.copy_(Xf)
+            yield X
+
+    want = [pod.pod_device(Xf, num=k, normalize=True)["s"] for Xf in final]
+    pipe = PodPipeline(small_set=0)
+    for out, s in zip(pipe.run(lazy(), num=k, normalize=True), want):
+        np.testing.assert_allclose(out["s"][:k], s[:k], rtol=1e-11)
+    pipe.close()
+    lanes = PodLanes()
+    for out, s in zip(lanes.run(lazy(), num=k, normalize=True), want):
+        np.testing.assert_allclose(out["s"][:k], s[:k], rtol=1e-11)
+
+
+_EXIT_CHILD = r"""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, {root!r})
+from romtime_amd import ops
+from romtime_amd.pipeline import PodPipeline
+rng = np.random.RandomState(3)
+sets = [ops.to_device(rng.standard_normal((5000, 48))) for _ in range(4)]
+pipe = PodPipeline(small_set=0)
+KEPT = pipe.map(sets, num=4, normalize=True)          # module global: alive when the interpreter exits
+OPEN = pipe.run(sets, num=4, normalize=True)          # and a generator that was never finished
+FIRST = next(OPEN)
+assert KEPT[0]["Q"].shape == (5000, 4) and float(KEPT[0]["Q"].abs().sum()) > 0
+print("child done", flush=True)
+"""
+
+
+def test_process_exits_cleanly_with_pipeline_results_alive():
+    """Results of PodPipeline held in module globals at interpreter exit, plus an unfinished generator: the process must
+    end with status 0.  (Round 2: blocks tagged with a CU-masked stream met torch's allocator teardown after the stream
+    had been destroyed.  Now everything handed out is allocated on the caller's stream; run ONCE, in a child.)"""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = subprocess.run([sys.executable, "-c", _EXIT_CHILD.format(root=root)], capture_output=True, text=True, timeout=300)
+    assert "child done" in res.stdout, res.stderr[-3000:]
+    assert res.returncode == 0, (res.returncode, res.stderr[-3000:])
