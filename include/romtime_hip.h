@@ -269,6 +269,13 @@ int rt_last_sweep_stats(rt_ctx* ctx, int64_t* stats4);
 #define RT_P1_CONVECTION 2
 #define RT_P1_TRILINEAR 3
 #define RT_P1_LOAD 4
+/* RT_P1_LOAD_P2: int f v with f the P2 interpolant of the data on every cell - what FEniCS integrates for an
+ * Expression(..., degree=2) (fom/heat.py:119 forcing; fom/base.py:452-495 lifting data), exact for quadratic f:
+ * out = coef h/3 (f_{i-1/2} + f_i + f_{i+1/2}).  state_mode 1 = n_states x (2 nx + 1) values (vertex k at 2k, midpoint
+ * of cell k at 2k+1), state_mode 3 = n_states x 3 coefficients of a0 + a1 x + a2 x^2 in the physical coordinate.
+ * Reproduces the reference's known-answer tables expected_mat_fh / expected_mat_fgh_time (tests/test_mpf1.py:288-302):
+ * forcing problems/mfp1.py:38-39; lifting vector = -h dg_dt(x_i) (fom/heat.py:131-169) = this kind with coef = -1. */
+#define RT_P1_LOAD_P2 5
 int rt_p1_local_assembly(rt_ctx* ctx, int kind, int64_t nx, const int64_t* rows, const int64_t* cols, int64_t m,
                          int64_t n_states, const double* h, const double* coef, int state_mode, const double* state,
                          double* out);

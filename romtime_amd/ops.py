@@ -275,13 +275,15 @@ def tracked_solve(K: torch.Tensor, b: torch.Tensor, Xinv: torch.Tensor = None):
     return bw, info, Xinv
 
 
-P1_KINDS = dict(mass=0, stiffness=1, convection=2, trilinear=3, load=4)
+P1_KINDS = dict(mass=0, stiffness=1, convection=2, trilinear=3, load=4, load_p2=5)
 
 
-def p1_local_assembly(kind: str, nx: int, rows, cols, h, coef=None, state=None, ramp=None) -> torch.Tensor:
+def p1_local_assembly(kind: str, nx: int, rows, cols, h, coef=None, state=None, ramp=None, poly=None) -> torch.Tensor:
     """Closed-form 1-D P1 operator values at the entries (rows[e], cols[e]) for every state: (n_states, m) table.
     ``h`` (n_states) cell sizes, ``coef`` (n_states) optional factors, ``state`` (n_states, nx + 1) nodal values or
-    ``ramp`` (n_states) amplitudes of amp * node / nx for the trilinear / load kinds.  rt_p1_local_assembly."""
+    ``ramp`` (n_states) amplitudes of amp * node / nx for the trilinear / load kinds.  ``load_p2`` (the exact integral
+    of degree-2 data, fom/heat.py:119): ``state`` is (n_states, 2 nx + 1) vertex / midpoint values, or ``poly``
+    (n_states, 3) the coefficients of a0 + a1 x + a2 x^2 in the physical coordinate.  rt_p1_local_assembly."""
     ctx = Context.current()
     rows = rows if isinstance(rows, torch.Tensor) else to_device_index(rows)
     cols = None if cols is None else (cols if isinstance(cols, torch.Tensor) else to_device_index(cols))
@@ -291,12 +293,18 @@ def p1_local_assembly(kind: str, nx: int, rows, cols, h, coef=None, state=None, 
     mode, st = 0, None
     if state is not None:
         st = to_device(state).contiguous()
-        if tuple(st.shape) != (n_states, nx + 1):
-            raise RomtimeHipError("p1_local_assembly: `state` must be (n_states, nx + 1)")
+        width = 2 * nx + 1 if kind == "load_p2" else nx + 1
+        if tuple(st.shape) != (n_states, width):
+            raise RomtimeHipError(f"p1_local_assembly: `state` must be (n_states, {width}) for kind {kind!r}")
         mode = 1
     elif ramp is not None:
         st = to_device(np.atleast_1d(ramp) if not isinstance(ramp, torch.Tensor) else ramp).contiguous()
         mode = 2
+    elif poly is not None:
+        st = to_device(poly).contiguous()
+        if tuple(st.shape) != (n_states, 3):
+            raise RomtimeHipError("p1_local_assembly: `poly` must be (n_states, 3)")
+        mode = 3
     out = torch.empty((n_states, m), dtype=torch.float64, device=h.device)
     ctx.check(ctx.lib.rt_p1_local_assembly(ctx.handle, P1_KINDS[kind], int(nx), _ptr(rows), _ptr(cols), m, n_states, _ptr(h),
                                            _ptr(coef), mode, _ptr(st), _ptr(out)), "rt_p1_local_assembly")

@@ -129,6 +129,96 @@ class MockSolver:
         return np.zeros(self.Nh) if entries is None else np.zeros(len(entries))
 
 
+class MockHeatEquation(MockSolver):
+    """The manufactured heat problem MFP1 (problems/mfp1.py:19-75) on a fixed or moving interval, in closed form.
+
+    ``mu`` keys: ``delta``, ``beta``, ``alpha_0`` (+ whatever ``Lt`` / ``dLt_dt`` take).  Dirichlet data
+    ``b0 = 1 - exp(-beta t)``, ``bL = b0 (1 + delta^2 L^2)`` and their time derivatives (mfp1.py:27-35), forcing
+    ``beta exp(-beta t)(1 + delta^2 x^2) - 2 delta^2 alpha_0 (1 - exp(-beta t))`` (mfp1.py:38-39), constant diffusivity
+    ``alpha_0`` (fom/heat.py:42-55).  The reference hands these to FEniCS as ``Expression(..., degree=2)``
+    (fom/heat.py:119, fom/base.py:452-495): each is interpolated at the vertices and the midpoint of every cell and the
+    product with the P1 test function integrated exactly, i.e. per cell
+
+        int f phi_l = h/6 (f_l + 2 f_m),     int f phi_r = h/6 (2 f_m + f_r)
+
+    (Simpson's rule on a cubic) - exact for the quadratic forcing, which the P1-interpolated rule of
+    ``MockSolver.assemble_forcing`` is not.  Pinned by the reference's known-answer tables ``expected_mat_fh`` /
+    ``expected_mat_fgh_time`` (tests/test_mpf1.py:288-302; tests/test_oracle_golden.py)."""
+
+    def __init__(self, domain, Lt=None, dLt_dt=None):
+        super().__init__(domain=domain, forcing_term=None, Lt=Lt)
+        self.dLt_dt = dLt_dt   # callable dL/dt (t, **mu) of the SCALE factor, or None (fom/base.py:407-412)
+        self.BDF_SCHEME = "1"
+
+    def assemble_stiffness(self, mu=None, t=None, entries=None):
+        h = self._h(mu, t)
+        elem = np.tile(mu["alpha_0"] / h * np.array([[1.0, -1.0], [-1.0, 1.0]]), (self.nx, 1, 1))
+        return self._assemble_matrix(elem, entries)
+
+    # -- the problem's data as polynomials in the physical coordinate ---------------------------------------------
+    def forcing_poly(self, mu, t):
+        """(a0, a1, a2) of the forcing a0 + a1 x + a2 x^2 (mfp1.py:38-39)."""
+        e = np.exp(-mu["beta"] * t)
+        d2 = mu["delta"] ** 2
+        return np.array([mu["beta"] * e - 2.0 * d2 * mu["alpha_0"] * (1.0 - e), 0.0, mu["beta"] * e * d2])
+
+    def boundary_data(self, mu, t):
+        """b0, bL, grad_g and the coefficients (d0, d1) of dg_dt = d0 + d1 x (fom/base.py:377-495)."""
+        L = self._L(mu, t)
+        dL = self.domain["L0"] * self.dLt_dt(t=t, **mu) if self.dLt_dt is not None else 0.0
+        e = np.exp(-mu["beta"] * t)
+        d2 = mu["delta"] ** 2
+        b0, bL = 1.0 - e, (1.0 - e) * (1.0 + d2 * L * L)
+        db0 = mu["beta"] * e
+        dbL = mu["beta"] * e * (1.0 + d2 * L * L) + 2.0 * (1.0 - e) * d2 * L * dL        # mfp1.py:35
+        d1 = (dbL - db0) / L + (b0 - bL) * dL / (L * L)     # linear interpolation + moving-boundary effect, base.py:413-421
+        return dict(b0=b0, bL=bL, grad_g=(bL - b0) / L, d0=db0, d1=d1)
+
+    def lifting_poly(self, mu, t):
+        """(a0, a1, 0) of dg_dt: the lifting vector is MINUS the degree-2 load of it at interior dofs."""
+        bd = self.boundary_data(mu, t)
+        return np.array([bd["d0"], bd["d1"], 0.0])
+
+    def lifting(self, mu, t):
+        bd = self.boundary_data(mu, t)
+        x, L = self.x_at(mu, t), self._L(mu, t)
+        return bd["bL"] * x / L + bd["b0"] * (L - x) / L
+
+    def exact_solution_at(self, mu, t):
+        x = self.x_at(mu, t)
+        return (1.0 - np.exp(-mu["beta"] * t)) * (1.0 + mu["delta"] ** 2 * x * x)          # mfp1.py:45
+
+    # -- degree-2 load vectors ---------------------------------------------------------------------------------------
+    def _p2_elements(self, poly, mu, t):
+        x, h = self.x_at(mu, t), self._h(mu, t)
+        f = lambda z: poly[0] + poly[1] * z + poly[2] * z * z
+        fl, fm, fr = f(x[:-1]), f(0.5 * (x[:-1] + x[1:])), f(x[1:])
+        return np.stack([h / 6.0 * (fl + 2.0 * fm), h / 6.0 * (2.0 * fm + fr)], axis=1)
+
+    def assemble_forcing(self, mu, t, entries=None):
+        return self._assemble_vector(self._p2_elements(self.forcing_poly(mu, t), mu, t), entries)
+
+    def assemble_lifting(self, mu, t, entries=None):
+        """-(int dg_dt v + alpha grad_g . grad v), fom/heat.py:131-169."""
+        bd = self.boundary_data(mu, t)
+        elem = self._p2_elements(self.lifting_poly(mu, t), mu, t)
+        flux = mu["alpha_0"] * bd["grad_g"]                 # int grad_g phi' over a cell: -/+ grad_g (cancels at interior dofs)
+        elem = -(elem + np.array([-flux, flux])[None, :])
+        return self._assemble_vector(elem, entries)
+
+    def assemble_rhs(self, mu, t, entries=None):
+        return self.assemble_forcing(mu, t, entries) + self.assemble_lifting(mu, t, entries)   # fom/heat.py:171-188
+
+    def p1_closed_form(self, mus, ts):
+        """As MockSolver.p1_closed_form, plus what ``rt_p1_local_assembly("load_p2", poly=...)`` needs for the two load
+        vectors: (nt, n_mu, 3) polynomial coefficients of the forcing and of dg_dt."""
+        out = _p1_closed_form(self, mus, ts)
+        out["alpha"] = np.broadcast_to(np.array([mu["alpha_0"] for mu in mus])[None, :], out["h"].shape).copy()
+        out["forcing_poly"] = np.array([[self.forcing_poly(mu, t) for mu in mus] for t in np.asarray(ts, dtype=float)])
+        out["lifting_poly"] = np.array([[self.lifting_poly(mu, t) for mu in mus] for t in np.asarray(ts, dtype=float)])
+        return out
+
+
 class MockBurgers(MockSolver):
     """Burgers/piston-type operators for the online loop (rom/rom.py:877-929).
 

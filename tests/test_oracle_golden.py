@@ -170,6 +170,71 @@ def test_closed_form_p1_operators_match_the_reference_known_answer_tables():
         np.testing.assert_array_almost_equal(Mh, expected_M, decimal=6)
 
 
+MFP1_FH = np.array([[0.0, 18.38874897, 8.71846778, 0.0], [0.0, 13.17828361, 6.00010814, 0.0],
+                    [0.0, 47.42510228, 17.611488, 0.0]])                                  # test_mpf1.py:288-294
+MFP1_FGH = np.array([[0.0, -24.29836526, -14.62808406, 0.0], [0.0, -17.56494639, -10.38677093, 0.0],
+                     [0.0, -65.64453323, -35.83091895, 0.0]])                             # test_mpf1.py:296-302
+
+
+def mfp1_samples():
+    from scipy.stats import uniform
+    from sklearn.model_selection import ParameterSampler
+
+    grid = {"delta": uniform(0.01, 1.99), "beta": uniform(1.0, 9.0), "alpha_0": uniform(0.01, 1.99)}  # test_mpf1.py:95-103
+    return list(ParameterSampler(param_distributions=grid, n_iter=3, random_state=np.random.RandomState(0)))
+
+
+def test_closed_form_load_vectors_match_the_reference_known_answer_tables():
+    """The forcing and lifting vectors of the heat problem (tests/test_mpf1.py:288-302: `expected_mat_fh`,
+    `expected_mat_fgh_time`; same solver, draws and t = 0 as the operator tables above).  FEniCS numbers the dofs of
+    this interval mesh from the right end, so the tables read right-to-left against the mock's left-to-right dofs.
+    The P1-interpolated load rule misses them in the second digit (9.2557 instead of 8.7185): they pin the exact
+    degree-2 rule."""
+    from romtime_amd.testing.mock import MockHeatEquation, MockSolver
+
+    solver = MockHeatEquation(domain={"L0": 2.0, "nx": 3, "T": 10.0, "nt": 500})
+    solver.setup()
+    for sample, fh_ref, fgh_ref in zip(mfp1_samples(), MFP1_FH, MFP1_FGH):
+        np.testing.assert_array_almost_equal(solver.assemble_forcing(mu=sample, t=0.0)[::-1], fh_ref, decimal=6)
+        np.testing.assert_array_almost_equal(solver.assemble_lifting(mu=sample, t=0.0)[::-1], fgh_ref, decimal=6)
+        np.testing.assert_allclose(solver.assemble_forcing(mu=sample, t=0.0)[::-1], fh_ref, rtol=2e-9)     # every printed digit
+        np.testing.assert_allclose(solver.assemble_lifting(mu=sample, t=0.0)[::-1], fgh_ref, rtol=2e-9)
+        entries = [(1,), (2,), (0,)]
+        np.testing.assert_array_equal(solver.assemble_forcing(sample, 0.0, entries=entries), solver.assemble_forcing(sample, 0.0)[[1, 2, 0]])
+    p1 = MockSolver(domain={"L0": 2.0, "nx": 3, "T": 10.0, "nt": 500}, forcing_term=lambda x, t, **mu: mu["beta"] * (1.0 + mu["delta"] ** 2 * x * x))
+    p1.setup()
+    assert abs(p1.assemble_forcing(mfp1_samples()[0], 0.0)[1] - 8.71846778) > 0.5        # what the tables rule out
+
+
+def test_heat_problem_mock_converges_to_its_exact_solution():
+    """The manufactured problem end to end on the fixed mesh (the reference's tests/test_mpf1.py solves it with FEniCS):
+    BDF1 with the closed-form operators, forcing and lifting vector; u_h + g_h against u_e = (1 - e^{-beta t})(1 +
+    delta^2 x^2) (mfp1.py:45).  The error is the O(dt) of BDF1 and halves with dt down to 5e-4: a wrong lifting or
+    forcing vector leaves an O(1) residue instead."""
+    from scipy.sparse.linalg import spsolve
+
+    from romtime_amd.testing.mock import MockHeatEquation
+
+    mu = dict(delta=1.0, beta=5.0, alpha_0=1.0)                                          # test_mpf1.py:83-91
+
+    def run(nx, nt, T=1.0):
+        fom = MockHeatEquation(domain={"L0": 2.0, "nx": nx, "T": T, "nt": nt})
+        fom.setup()
+        dt, u = fom.dt, np.zeros(nx + 1)
+        worst = 0.0
+        for step in range(1, nt + 1):
+            t = step * dt
+            M, A = fom.assemble_mass(mu, t), fom.assemble_stiffness(mu, t)
+            rhs = M.dot(u) + dt * fom.assemble_rhs(mu, t)
+            rhs[0] = rhs[-1] = 0.0
+            u = spsolve((M + dt * A).tocsc(), rhs)
+            worst = max(worst, np.abs(u + fom.lifting(mu, t) - fom.exact_solution_at(mu, t)).max())
+        return worst
+
+    e1, e2, e3 = run(40, 400), run(40, 800), run(40, 1600)      # measured: 3.0e-3, 1.35e-3, 5.5e-4
+    assert e2 < 0.6 * e1 and e3 < 0.6 * e2 and e3 < 1e-3        # first order in time, nothing left over
+
+
 def test_closed_form_moving_mesh_stiffness_matches_the_reference_table():
     """tests/test_moving_mesh.py:102-150: stiffness of the moving-mesh solver (nx = 5, L(t) = 1 + sin(omega t),
     alpha_0 = 0.5) at t = 0 and t = 5; the reference's CSR keeps two explicit zeros in the Dirichlet rows, which

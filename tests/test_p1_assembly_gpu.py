@@ -107,3 +107,51 @@ def test_hyper_reduced_tables_built_on_the_device():
     for b in range(len(mus)):
         ref = oracle.hrom_solve(host["mass"], host["lin"], host["nl"], host["rhs"], b, r, nt, host["dt"], host["bdf2"])
         assert np.linalg.norm(uN[b].T - ref) <= 1e-10 * np.linalg.norm(ref), b
+
+
+def test_degree2_load_vectors_on_the_device():
+    """RT_P1_LOAD_P2: the exact degree-2 load rule on the device against (1) the reference's literal
+    forcing / lifting tables tests/test_mpf1.py:288-302 - polynomial mode and vertex/midpoint-value mode - and (2) the
+    NumPy closed form (MockHeatEquation, pinned to the same tables in tests/test_oracle_golden.py) on a moving mesh at
+    t > 0, where the moving-boundary term of dg_dt and the time-dependent data are live."""
+    from romtime_amd import ops
+    from romtime_amd.testing.mock import MockHeatEquation
+    from tests.test_oracle_golden import MFP1_FGH, MFP1_FH, mfp1_samples
+
+    nx, L = 3, 2.0
+    fom = MockHeatEquation(domain={"L0": L, "nx": nx, "T": 10.0, "nt": 500})
+    fom.setup()
+    samples = mfp1_samples()
+    cf = fom.p1_closed_form(samples, [0.0])
+    dofs = np.arange(nx + 1)
+    fh = ops.p1_local_assembly("load_p2", nx, dofs, None, cf["h"][0], poly=cf["forcing_poly"][0]).cpu().numpy()
+    fgh = ops.p1_local_assembly("load_p2", nx, dofs, None, cf["h"][0], coef=-np.ones(3), poly=cf["lifting_poly"][0]).cpu().numpy()
+    np.testing.assert_array_almost_equal(fh[:, ::-1], MFP1_FH, decimal=6)       # FEniCS numbers this mesh right to left
+    np.testing.assert_array_almost_equal(fgh[:, ::-1], MFP1_FGH, decimal=6)
+    np.testing.assert_allclose(fh[:, ::-1], MFP1_FH, rtol=2e-9)
+    np.testing.assert_allclose(fgh[:, ::-1], MFP1_FGH, rtol=2e-9)
+    # the same through explicit vertex / midpoint values (what a FOM with non-polynomial data would hand over)
+    xs = np.linspace(0.0, L, 2 * nx + 1)
+    vals = np.array([p[0] + p[1] * xs + p[2] * xs * xs for p in cf["forcing_poly"][0]])
+    fh2 = ops.p1_local_assembly("load_p2", nx, dofs, None, cf["h"][0], state=vals).cpu().numpy()
+    np.testing.assert_allclose(fh2, fh, rtol=1e-14, atol=1e-15)
+    # moving mesh, t > 0, picked entries, many states in one launch
+    nx = 200
+    mov = MockHeatEquation(domain={"L0": 1.5, "nx": nx, "T": 2.0, "nt": 40}, Lt=lambda t, **mu: 1.0 - 0.3 * np.sin(mu["omega"] * t),
+                           dLt_dt=lambda t, **mu: -0.3 * mu["omega"] * np.cos(mu["omega"] * t))
+    mov.setup()
+    mus = [dict(s, omega=1.0 + q) for q, s in enumerate(samples)]
+    ts = mov.dt * np.arange(1, 41)
+    cf = mov.p1_closed_form(mus, ts)
+    rng = np.random.RandomState(4)
+    pick = np.r_[0, 1, rng.choice(np.arange(2, nx - 1), 30, replace=False), nx - 1, nx]
+    flat = lambda a: a.reshape(-1, *a.shape[2:])
+    F = ops.p1_local_assembly("load_p2", nx, pick, None, flat(cf["h"]), poly=flat(cf["forcing_poly"])).cpu().numpy()
+    G = ops.p1_local_assembly("load_p2", nx, pick, None, flat(cf["h"]), coef=-np.ones(ts.size * len(mus)),
+                              poly=flat(cf["lifting_poly"])).cpu().numpy()
+    entries = [(int(i),) for i in pick]
+    for it, t in enumerate(ts):
+        for j, mu in enumerate(mus):
+            ref_f, ref_g = mov.assemble_forcing(mu, t, entries=entries), mov.assemble_lifting(mu, t, entries=entries)
+            np.testing.assert_allclose(F[it * len(mus) + j], ref_f, rtol=1e-12, atol=1e-14 * np.abs(ref_f).max())
+            np.testing.assert_allclose(G[it * len(mus) + j], ref_g, rtol=1e-11, atol=1e-13 * np.abs(ref_g).max())
