@@ -75,23 +75,40 @@ def build_local_matrix(rank, world, n_h, n, device):
     return X.contiguous()
 
 
-def cpu_baseline(n, r, sample_rows):
-    """The oracle's orth (column norms + divide + dgesvd + energy + truncation, pod.py:31-57) on the
-    first `sample_rows` rows of the same synthetic matrix, all host cores."""
+def cpu_baseline(X_host, r, device_result=None):
+    """The oracle's orth (column norms + divide + dgesvd + energy + truncation, pod.py:31-57) on the host copy of the
+    workload's own snapshot matrix (or its first rows), all host cores.  With ``device_result`` (Q on the device, s on
+    the host, of one of the timed PODs of the SAME matrix) the dgesvd result is not thrown away: `parity` is the
+    distance between the two at the stated size."""
     from oracle import romtime_oracle as oracle
 
-    mix = mixing_matrix(n, "cpu")
-    X = make_chunk(0, sample_rows, n, mix, "cpu").numpy()
+    sample_rows, n = X_host.shape
     cores = min(16, len(os.sched_getaffinity(0)))  # a 1-GPU box gives this process a 16-core share
     from threadpoolctl import threadpool_limits
 
     with threadpool_limits(limits=cores):
         t0 = time.perf_counter()
-        Q, s, energy = oracle.orth(X, num=r, normalize=True)
+        Q, s, energy = oracle.orth(X_host, num=r, normalize=True)
         dt = time.perf_counter() - t0
-    return dict(value=sample_rows * n / dt, unit="snapshot-DoF/s", cores=cores, kind="port",
-                sample=f"oracle.orth (scipy dgesvd) on {'the whole' if sample_rows >= N_H else 'the first'} {sample_rows} x {n} rows of the workload, "
-                       f"{dt:.2f} s, numpy {np.__version__}")
+    out = dict(value=sample_rows * n / dt, unit="snapshot-DoF/s", cores=cores, kind="port",
+               sample=f"oracle.orth (scipy dgesvd) on {'the whole' if sample_rows >= N_H else 'the first'} {sample_rows} x {n} rows of the workload, "
+                      f"{dt:.2f} s, numpy {np.__version__}")
+    if device_result is not None:
+        Qd, sd = device_result["Q"].cpu().numpy(), np.asarray(device_result["s"])
+        eps = np.finfo(float).eps
+        bar = 2e-13 * s[0] + 8 * eps * s[0] ** 2 / np.maximum(s, 1e-300)      # the bar of tests/test_surface.py
+        with threadpool_limits(limits=cores):
+            resid = Qd - Q @ (Q.T @ Qd)                                        # sine of the largest principal angle
+            col = np.minimum(np.linalg.norm(Qd - Q, axis=0), np.linalg.norm(Qd + Q, axis=0)) if Qd.shape == Q.shape else [np.inf]
+            out["parity"] = dict(
+                sigma_max_rel=float(np.abs(sd - s).max() / s[0]), sigma_within_test_bar=bool(np.all(np.abs(sd - s) <= bar)),
+                subspace_dist=float(np.linalg.norm(resid, 2)), max_column_dist_up_to_sign=float(np.max(col)),
+                kept_modes_equal=bool(Qd.shape[1] == Q.shape[1]), kept_modes=int(Q.shape[1]),
+                energy_max_abs=float(np.abs(np.asarray(device_result["energy"]) - energy).max()),
+                orthonormality=float(np.abs(Qd.T @ Qd - np.eye(Qd.shape[1])).max()),
+                note="device POD (one of the timed steps) vs scipy dgesvd on the same 1e6 x 512 matrix; sigma_i below "
+                     "sqrt(eps) sigma_1 carry eps sigma_1^2 / sigma_i from the Gram route (the test bar)")
+    return out
 
 
 def secondary_online_sweep(ctx, device, nt, n_mu, r, n_h, with_cpu):
@@ -179,6 +196,10 @@ def secondary_online_sweep(ctx, device, nt, n_mu, r, n_h, with_cpu):
             ref, _ = oracle.rom_solve_nonlinear(small, V, mus[0], solver=oracle.reduced_solve)   # GMRES as the reference
             cpu_direct = (time.perf_counter() - t0) / n_direct
             err_direct = float(np.linalg.norm(uN_direct[0, :n_direct].cpu().numpy().T - ref) / np.linalg.norm(ref))
+            # the same loop with an exact dense solver: the reference's GMRES stops at a 1e-10 residual (rom.py:36) and is
+            # itself ~1e-7 away from the solution of its own systems here, so THIS is the distance the 1e-10 bar is about
+            exact, _ = oracle.rom_solve_nonlinear(small, V, mus[0], solver=np.linalg.solve)
+            err_exact = float(np.linalg.norm(uN_direct[0, :n_direct].cpu().numpy().T - exact) / np.linalg.norm(exact))
             n_h_steps = 2000
             cut = lambda term: dict(term, F=term["F"][:n_h_steps])
             t0 = time.perf_counter()
@@ -189,7 +210,8 @@ def secondary_online_sweep(ctx, device, nt, n_mu, r, n_h, with_cpu):
         out["cpu_baseline"] = {
             "direct": dict(value=1.0 / cpu_direct, unit="reduced timesteps/s", cores=cores, kind="port",
                            sample=f"oracle.rom_solve_nonlinear (5 csr.dot + matmul projections + GMRES per step, rom.py:877-929) "
-                                  f"for 1 mu x {n_direct} steps of the workload", rel_l2_device_vs_oracle=err_direct),
+                                  f"for 1 mu x {n_direct} steps of the workload", rel_l2_device_vs_oracle=err_direct,
+                           rel_l2_device_vs_exact_solver_oracle=err_exact),
             "hyper_reduced": dict(value=1.0 / cpu_h, unit="reduced timesteps/s", cores=cores, kind="port",
                                   sample=f"oracle.hrom_solve (theta solves + dense solve per step, deim.py:416-452) for 1 mu x "
                                          f"{n_h_steps} steps of the workload", rel_l2_device_vs_oracle=err_h),
@@ -403,6 +425,7 @@ def main():
         barrier()
         elapsed = time.perf_counter() - t0
         out = dict(passes=outs[-1]["passes"])
+        kept = dict(Q=outs[-1]["Q"], s=outs[-1]["s"], energy=outs[-1]["energy"])   # for cpu_baseline.parity
         gram_ms = list(pipe.gram_kernel_ms)
         stage_ms = dict(pipe.last_stage_ms, sets_recomputed_on_regular_route=float(pipe.recomputed),
                         eigensolver_cus=float(pipe.eig_cus))
@@ -442,6 +465,7 @@ def main():
         elapsed = time.perf_counter() - t0
         ctx.set_profile(False)
         stage_ms = dict(pod.stage_timings())   # stream events of the last step, resolved after the timed region
+        kept = dict(Q=out["Q"], s=out["s"], energy=out["energy"])
         counts = [ctx.counter(c) for c in FALLBACK_COUNTERS[:3]] + [0]
 
     t = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -488,7 +512,10 @@ def main():
         line["roofline"] = roofline
         line["fallback_counters"] = fallback
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(n, r, min(args.cpu_sample_rows, n_h))
+            rows = min(args.cpu_sample_rows, n_h)
+            X_host = X[:rows].cpu().numpy()          # the workload's own matrix (device and host RNG streams differ)
+            line["cpu_baseline"] = cpu_baseline(X_host, r, device_result=kept if rows == n_h else None)
+            del X_host
         if world == 1 and not args.no_secondary:
             del X, out
             torch.cuda.empty_cache()

@@ -23,7 +23,11 @@ __global__ void sweep_rows_kernel(const long* __restrict__ indptr, long N, int* 
 // kval[b][e] = bdf*mass[e] + dt*(sum_q coef[b][q]*terms[q][e] + u*(b, row_of[e])*tril[e]),  u* = 2 uh - uh_prev
 // One thread per entry e for ALL parameter points: the Q + 2 operator arrays are read once (not once per parameter
 // point through the L2: 132 -> ~55 us at 5e5 entries x 32 points), the writes stream out vector by vector.
+// COEF_LDS: the step's coefficient table coef[B][Q] is staged in LDS (the common case: 32 points x a handful of terms);
+// a table beyond SV_LDS_BYTES (e.g. 64 points x 200 terms) is read through the L1/L2 instead - any B and Q work.
 constexpr int SV_QMAX = 8;
+constexpr long SV_LDS_BYTES = 32 * 1024;
+template <bool COEF_LDS>
 __global__ __launch_bounds__(256) void sweep_values_kernel(const double* __restrict__ mass,
                                                            const double* __restrict__ terms, int Q,
                                                            const double* __restrict__ coef,
@@ -34,8 +38,10 @@ __global__ __launch_bounds__(256) void sweep_values_kernel(const double* __restr
                                                            long N, int B, double bdf, double dt,
                                                            double* __restrict__ kval) {
   extern __shared__ double s_coef[];   // [B][Q]
-  for (int i = threadIdx.x; i < B * Q; i += blockDim.x) s_coef[i] = coef[i];
-  __syncthreads();
+  if (COEF_LDS) {
+    for (int i = threadIdx.x; i < B * Q; i += blockDim.x) s_coef[i] = coef[i];
+    __syncthreads();
+  }
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= nnz) return;
   double tq[SV_QMAX];
@@ -49,8 +55,9 @@ __global__ __launch_bounds__(256) void sweep_values_kernel(const double* __restr
     double s = 0.0;
 #pragma unroll
     for (int q = 0; q < SV_QMAX; ++q)
-      if (q < Q) s = fma(s_coef[b * Q + q], tq[q], s);
-    for (int q = SV_QMAX; q < Q; ++q) s = fma(s_coef[b * Q + q], terms[(long)q * nnz + e], s);   // more terms than registers
+      if (q < Q) s = fma(COEF_LDS ? s_coef[b * Q + q] : coef[b * Q + q], tq[q], s);
+    for (int q = SV_QMAX; q < Q; ++q)                                             // more terms than registers
+      s = fma(COEF_LDS ? s_coef[b * Q + q] : coef[b * Q + q], terms[(long)q * nnz + e], s);
     if (tril) {
       const double u = uh[(long)b * N + row];
       const double us = extrapolate ? 2.0 * u - uhp[(long)b * N + row] : u;
@@ -184,9 +191,14 @@ extern "C" int rt_rom_bdf_sweep(rt_ctx* ctx, const rt_sweep_desc* d, double* uN_
 
   for (long step = 0; step < nt; ++step) {
     const bool second = d->bdf2 && step > 0;
-    hipLaunchKernelGGL(sweep_values_kernel, dim3((unsigned)((nnz + 255) / 256)), dim3(256), sizeof(double) * B * Q, st,
-                       d->mass_values, d->term_values, Q, Q ? d->term_coef + step * B * Q : nullptr, d->tril_values,
-                       row_of, uh, uhp, d->bdf2 ? 1 : 0, nnz, N, (int)B, second ? 1.5 : 1.0, d->dt, kval);
+    if ((long)sizeof(double) * B * Q <= SV_LDS_BYTES)
+      hipLaunchKernelGGL(sweep_values_kernel<true>, dim3((unsigned)((nnz + 255) / 256)), dim3(256), sizeof(double) * B * Q,
+                         st, d->mass_values, d->term_values, Q, Q ? d->term_coef + step * B * Q : nullptr, d->tril_values,
+                         row_of, uh, uhp, d->bdf2 ? 1 : 0, nnz, N, (int)B, second ? 1.5 : 1.0, d->dt, kval);
+    else
+      hipLaunchKernelGGL(sweep_values_kernel<false>, dim3((unsigned)((nnz + 255) / 256)), dim3(256), 0, st,
+                         d->mass_values, d->term_values, Q, d->term_coef + step * B * Q, d->tril_values, row_of, uh, uhp,
+                         d->bdf2 ? 1 : 0, nnz, N, (int)B, second ? 1.5 : 1.0, d->dt, kval);
     RT_HIP_CHECK(ctx, hipGetLastError());
     rc = rt_project_fused(ctx, d->indptr, d->indices, kval, 1, nnz, B, N, d->V, r, r, KN, stage_table, banded);
     if (rc != RT_OK) return rc;

@@ -92,6 +92,34 @@ def test_c5_direct_sweep_full_horizon_reduced_N():
     _report(config="C5 direct sweep 1e4 steps N=3000 r=24", rel_l2=worst, **stats)
 
 
+def test_c5_direct_sweep_trajectory_at_full_size():
+    """rt_rom_bdf_sweep at config 5's own size - N = 1e5, r = 80, 32 parameter points - for 50 BDF2 steps against the
+    oracle's restatement of the reference loop (rom.py:430-555, 877-929: five csr.dot + matmul projections per step)
+    with an EXACT dense solver, two parameter points, whole reduced trajectory at the north star's 1e-10.  (The
+    residual test below validates the solves; this one validates the projections and the loop too.)"""
+    from romtime_amd._lib import Context
+    from romtime_amd.sweep import rom_bdf_sweep
+    from romtime_amd.testing.mock import AffineBurgers
+    from romtime_amd.testing.workloads import c5_direct
+
+    nt, n_mu = 50, 32
+    fom, V, mus, d = c5_direct(nt=nt, n_mu=n_mu)
+    uN = rom_bdf_sweep(V, d["indptr"], d["indices"], d["mass"], d["terms"], d["term_coef"], d["tril"], d["rhs_terms"],
+                       d["rhs_coef"], d["dt"], bdf2=True)
+    stats = Context.current().sweep_stats()
+    uN = uN.cpu().numpy()
+    assert uN.shape == (n_mu, nt, 80)
+    worst = 0.0
+    for b in (0, 31):
+        ref, _ = oracle.rom_solve_nonlinear(fom, V, mus[b], solver=np.linalg.solve)
+        whole, last = _rel(uN[b].T, ref), _rel(uN[b, -1], ref[:, -1])
+        worst = max(worst, whole, last)
+        assert whole <= 1e-10 and last <= 1e-10, (b, whole, last)
+        assert np.abs(ref).max() > 1e-5
+    assert stats["solves"] == nt * n_mu and stats["lu_fallbacks"] == 0, stats
+    _report(config="C5 direct sweep 50 steps N=1e5 r=80 32 mu vs exact-solver oracle", rel_l2=worst, **stats)
+
+
 def test_c5_reduced_residual_inside_reference_acceptance_ball():
     """The reference accepts any u_N with ||K_N u_N - b_N|| <= 1e-10 ||b_N|| (GMRES, rom.py:36,492, info ignored).
     The device's answers at full size (N = 1e5, r = 80, 32 mu) satisfy that at every step: K_N and b_N are rebuilt

@@ -379,6 +379,29 @@ def test_device_sweep_matches_oracle_loop(bdf2):
         assert np.abs(ref_rom).max() > 1e-4  # a non-trivial trajectory
 
 
+def test_device_sweep_takes_any_number_of_terms_and_points():
+    """The step's coefficient table coef[n_mu][Q] is staged in LDS when it is small; a large one (60 points x 150 terms
+    = 72 KB, beyond the 64 KB a launch may ask for: round 2's kernel failed with RT_ERR_HIP there) is read
+    from memory instead.  Same model both ways: every affine term split into 50 equal parts."""
+    from romtime_amd.sweep import rom_bdf_sweep
+    from romtime_amd.testing.mock import AffineBurgers
+
+    fom = AffineBurgers(N=1200, nt=12, dt=2e-3, bdf2=True, seed=4)
+    xs = (np.arange(fom.Nh) + 0.5) / fom.Nh
+    V, _ = np.linalg.qr(np.stack([np.sin((k + 1) * np.pi * xs) for k in range(10)], axis=1))
+    mus = [dict(alpha=0.5 + 0.01 * i, beta=1.0 - 0.01 * i, delta=0.3 + 0.005 * i, omega=7.0 + 0.1 * i) for i in range(60)]
+    d = fom.descriptor(mus)
+    args = lambda terms, coef: (V, d["indptr"], d["indices"], d["mass"], terms, coef, d["tril"], d["rhs_terms"], d["rhs_coef"], d["dt"])
+    small = rom_bdf_sweep(*args(d["terms"], d["term_coef"]), bdf2=True).cpu().numpy()
+    parts = 50
+    terms = np.repeat(d["terms"], parts, axis=0) / parts                 # 150 x nnz
+    coef = np.repeat(d["term_coef"], parts, axis=2)                      # nt x 60 x 150
+    big = rom_bdf_sweep(*args(terms, coef), bdf2=True).cpu().numpy()
+    assert np.linalg.norm(big - small) <= 1e-11 * np.linalg.norm(small)
+    ref, _ = oracle.rom_solve_nonlinear(fom, V, mus[7], solver=np.linalg.solve)
+    assert np.linalg.norm(big[7].T - ref) <= 1e-10 * np.linalg.norm(ref)
+
+
 def test_hyper_reduced_sweep_synthetic_and_singular_system(ops):
     """rt_hrom_bdf_sweep on random interpolation terms against oracle.hrom_solve, BDF1 and BDF2, r not a multiple of
     16; one parameter point gets an identically zero K_N: its inverse tracking fails, the device-side LU fallback
