@@ -269,6 +269,22 @@ class PodPipeline:
         self._admitted = 0
         depth = max(depth, self.world + 1)       # enough sets in flight for every rank's eigensolver stream to have one
 
+        def after_producer():
+            ready = torch.cuda.Event()
+            ready.record(main)
+            for st in (self.sG, self.sE, self.sC):
+                if st is not None:
+                    st.wait_event(ready)
+
+        # A list / tuple exists before the run: ONE event orders the pipeline's streams after whatever produced it.  Any
+        # other iterable may produce a set on the caller's stream at the moment it is asked for it: one event per set.
+        # (Per set on the LEGACY DEFAULT stream that costs the overlap - an event recorded on the null stream completes
+        # only when every blocking stream has drained, the CU-masked ones included: 9.6 instead of 5.8 ms per POD of
+        # 1e6 x 512 - so a lazy producer should run under a stream of its own, `with torch.cuda.stream(s): ...`.)
+        materialised = isinstance(snapshot_sets, (list, tuple))
+        if materialised:
+            after_producer()
+
         def admit():
             try:
                 X = next(it)
@@ -294,11 +310,8 @@ class PodPipeline:
                 # allocated here, on the caller's stream (see shutdown()).
                 item["Q"] = torch.empty((X.shape[0], item["k"]), dtype=torch.float64, device=X.device)
                 item["colnorm"] = torch.empty(n, dtype=torch.float64, device=X.device)
-                ready = torch.cuda.Event()
-                ready.record(main)
-                for st in (self.sG, self.sE, self.sC):
-                    if st is not None:
-                        st.wait_event(ready)
+                if not materialised:
+                    after_producer()
                 self._gram(item)
                 self._eig(item)
             return item
@@ -420,6 +433,12 @@ class PodLanes:
         it = iter(snapshot_sets)
         pending = collections.deque()
         admitted = 0
+        materialised = isinstance(snapshot_sets, (list, tuple))     # see PodPipeline._run
+        if materialised:
+            ready = torch.cuda.Event()
+            ready.record(main)
+            for st in self.streams:
+                st.wait_event(ready)
 
         def admit():
             nonlocal admitted
@@ -434,9 +453,10 @@ class PodLanes:
             item = dict(X=X, num=num, tol=tol, k=k, normalize=bool(normalize), direct=not (3 <= n <= 512))
             if not item["direct"]:
                 lane = admitted % len(self.streams)
-                ready = torch.cuda.Event()       # a lazy iterable produces this set on the caller's stream just now
-                ready.record(main)
-                self.streams[lane].wait_event(ready)
+                if not materialised:
+                    ready = torch.cuda.Event()   # a lazy iterable produces this set on the caller's stream just now
+                    ready.record(main)
+                    self.streams[lane].wait_event(ready)
                 self._enqueue(item, lane)
             admitted += 1
             pending.append(item)
