@@ -164,8 +164,42 @@ class DiscreteEmpiricalInterpolation(Reductor):
 
     def tree_walk(self, ts, normalize=True, num_mu=None, num_t=None, tol_mu=None, tol_t=None, num_snapshots=None,
                   mu_space=None):
-        """POD in time for every sampled mu, then POD of the concatenation (deim.py:279-355)."""
+        """POD in time for every sampled mu, then POD of the concatenation (deim.py:279-355).
+
+        The time-level PODs are a sequence of independent small PODs: every parameter's snapshot set is assembled by
+        the FOM callback on the host, uploaded once and run through the device's POD lanes (``walks.pod_sequence``);
+        the per-parameter bases stay on the device, where they are concatenated for the mu-level POD.  Only the final
+        basis and the spectra of the report come back.  A subclass that overrides ``walk_time`` keeps the plain loop."""
+        from . import walks
+
         space = mu_space if mu_space else self.build_sampling_space(num=num_snapshots, rnd=self.random_state)
+        off = self.report[Stage.OFFLINE]
+        if type(self).walk_time is not DiscreteEmpiricalInterpolation.walk_time:
+            return self._tree_walk_host(space, ts, normalize, num_mu, num_t, tol_mu, tol_t)
+        indices = []
+
+        def time_level_sets():
+            for mu in space:
+                mu_idx, mu = self.add_mu(step=Stage.OFFLINE, mu=mu)
+                indices.append(mu_idx)
+                yield walks.upload(self._time_level_snapshots(mu, ts))
+
+        per_mu = []
+        for i, out in enumerate(walks.pod_sequence(time_level_sets(), num=num_t, tol=tol_t, normalize=False)):
+            mu_idx = indices[i]
+            off.setdefault(self.SPECTRUM_TIME, {})[mu_idx] = out["s"]
+            off.setdefault(self.ENERGY_TIME, {})[mu_idx] = out["energy"]
+            off.setdefault(self.BASIS_TIME, {})[mu_idx] = out["Q"].shape[1]
+            per_mu.append(out["Q"])
+        top = walks.pod_of_stack(per_mu, num=num_mu, tol=tol_mu, normalize=normalize)
+        off[self.BASIS_AFTER_WALK] = top["stacked_columns"]
+        off[self.SPECTRUM_MU] = top["s"]
+        off[self.ENERGY_MU] = top["energy"]
+        off[self.BASIS_FINAL] = top["Q"].shape[1]
+        return top["Q"].cpu().numpy(), top["s"]
+
+    def _tree_walk_host(self, space, ts, normalize, num_mu, num_t, tol_mu, tol_t):
+        """The reference's loop as it stands (deim.py:330-349): one ``walk_time`` call per parameter."""
         off = self.report[Stage.OFFLINE]
         per_mu = []
         for mu in space:
@@ -183,12 +217,16 @@ class DiscreteEmpiricalInterpolation(Reductor):
         off[self.BASIS_FINAL] = basis.shape[1]
         return basis, sigmas_mu
 
-    def walk_time(self, mu, ts, normalize=True, num=None, tol=None):
-        """Time-level POD at frozen mu; never normalised at this level (deim.py:357-397)."""
+    def _time_level_snapshots(self, mu, ts):
+        """N_h x n_t snapshot matrix of one parameter (host; the FOM callback assembles it), deim.py:384-389."""
         snapshots = np.array([self.assemble_snapshot(mu, t) for t in ts]).T
         if self.TYPE == EmpiricalInterpolation.MDEIM:
             snapshots[0, :] = 0.0  # boundary entry does not matter (deim.py:388-389)
-        return orth(snapshots=snapshots, num=num, tol=tol, normalize=False)
+        return snapshots
+
+    def walk_time(self, mu, ts, normalize=True, num=None, tol=None):
+        """Time-level POD at frozen mu; never normalised at this level (deim.py:357-397)."""
+        return orth(snapshots=self._time_level_snapshots(mu, ts), num=num, tol=tol, normalize=False)
 
     def _assemble_functional(self, mu, t):
         return functional_to_array(self.assemble(mu=mu, t=t))

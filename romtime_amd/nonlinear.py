@@ -13,7 +13,6 @@ import numpy as np
 from .base import Reductor
 from .conventions import EmpiricalInterpolation, RomParameters, Stage, Treewalk
 from .mdeim import MatrixDiscreteEmpiricalInterpolation, sorted_topology
-from .pod import orth
 from .utils import bilinear_to_csr, eliminate_zeros
 
 
@@ -78,34 +77,48 @@ class MatrixDiscreteEmpiricalInterpolationNonlinear(MatrixDiscreteEmpiricalInter
 
     def tree_walk(self, ts, normalize=True, num_mu=None, num_t=None, num_basis=None, tol_mu=None, tol_t=None,
                   tol_basis=None, num_snapshots=None, mu_space=None):
+        """Three levels (nonlinear.py:320-403), all on the device: per parameter the basis-level PODs of every time step
+        run as one sequence through the POD lanes, their bases are concatenated on the device for the time-level POD,
+        and the per-parameter results again for the mu level (``walks``)."""
+        from . import walks
+
         space = mu_space if mu_space else self.build_sampling_space(num=num_snapshots, rnd=self.random_state)
         off = self.report[Stage.OFFLINE]
         per_mu = []
         for mu in space:
             mu_idx, mu = self.add_mu(step=Stage.OFFLINE, mu=mu)
-            basis_t, sigmas_t, energy_t = self.walk_time(mu=mu, ts=ts, num_t=num_t, tol_t=tol_t, normalize=normalize)
-            off.setdefault(self.SPECTRUM_TIME, {})[mu_idx] = sigmas_t
-            off.setdefault(self.ENERGY_TIME, {})[mu_idx] = energy_t
-            off.setdefault(self.BASIS_TIME, {})[mu_idx] = basis_t.shape[1]
-            per_mu.append(basis_t)
-        stacked = np.hstack(per_mu)
-        off[self.BASIS_AFTER_WALK] = stacked.shape[1]
-        basis, sigmas_mu, energy_mu = orth(snapshots=stacked, num=num_mu, tol=tol_mu, normalize=normalize)
-        off[self.SPECTRUM_MU] = sigmas_mu
-        off[self.ENERGY_MU] = energy_mu
-        off[self.BASIS_FINAL] = basis.shape[1]
-        return basis, sigmas_mu
+            out = self._walk_time_device(mu=mu, ts=ts, num_t=num_t, tol_t=tol_t, normalize=normalize)
+            off.setdefault(self.SPECTRUM_TIME, {})[mu_idx] = out["s"]
+            off.setdefault(self.ENERGY_TIME, {})[mu_idx] = out["energy"]
+            off.setdefault(self.BASIS_TIME, {})[mu_idx] = out["Q"].shape[1]
+            per_mu.append(out["Q"])
+        top = walks.pod_of_stack(per_mu, num=num_mu, tol=tol_mu, normalize=normalize)
+        off[self.BASIS_AFTER_WALK] = top["stacked_columns"]
+        off[self.SPECTRUM_MU] = top["s"]
+        off[self.ENERGY_MU] = top["energy"]
+        off[self.BASIS_FINAL] = top["Q"].shape[1]
+        return top["Q"].cpu().numpy(), top["s"]
+
+    def _walk_time_device(self, mu, ts, normalize=True, num_t=None, tol_t=None):
+        """POD over psi at every t (a sequence of independent PODs: the lanes), then POD over time of the concatenated
+        bases, built on the device (nonlinear.py:405-468; the reference passes num_t / tol_t to both levels)."""
+        from . import walks
+
+        u_n = self.u_n
+
+        def basis_level_sets():
+            for t in ts:
+                snapshots = np.array([self.assemble_snapshot(mu=mu, t=t, u_n=u_n[:, i]) for i in range(u_n.shape[1])]).T
+                snapshots[0, :] = 0.0
+                yield walks.upload(snapshots)
+
+        per_t = [out["Q"] for out in walks.pod_sequence(basis_level_sets(), num=num_t, tol=tol_t, normalize=normalize)]
+        return walks.pod_of_stack(per_t, num=num_t, tol=tol_t, normalize=normalize)
 
     def walk_time(self, mu, ts, normalize=True, num_t=None, tol_t=None, num_basis=None, tol_basis=None):
         """POD over psi at every t, then POD over time (nonlinear.py:405-468)."""
-        u_n = self.u_n
-        per_t = []
-        for t in ts:
-            snapshots = np.array([self.assemble_snapshot(mu=mu, t=t, u_n=u_n[:, i]) for i in range(u_n.shape[1])]).T
-            snapshots[0, :] = 0.0
-            phi_psi, _, _ = orth(snapshots=snapshots, num=num_t, tol=tol_t, normalize=normalize)
-            per_t.append(phi_psi)
-        return orth(snapshots=np.hstack(per_t), num=num_t, tol=tol_t, normalize=normalize)
+        out = self._walk_time_device(mu=mu, ts=ts, normalize=normalize, num_t=num_t, tol_t=tol_t)
+        return out["Q"].cpu().numpy(), out["s"], out["energy"]
 
     def assemble_snapshot(self, mu, t, u_n):
         return eliminate_zeros(self._assemble_matrix(mu, t, u_n)).data

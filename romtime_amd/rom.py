@@ -23,7 +23,6 @@ import torch
 from . import ops
 from .base import Reductor
 from .conventions import BDF, OperatorType, PistonParameters, RomParameters, Stage, Treewalk, TreewalkNonlinear
-from .pod import orth
 from .storage import RomSolutionsStorage
 from .utils import CsrPattern, bilinear_to_csr, function_to_array, functional_to_array, is_matrix_like
 
@@ -154,45 +153,61 @@ class RomConstructor(Reductor):
         off = self.report[Stage.OFFLINE]
         tol_t = tolerances.get(RomParameters.TOL_TIME, None)
         tol_mu = tolerances.get(RomParameters.TOL_MU, None)
-        fom_solutions, per_mu, per_mu_nl = dict(), [], []
-        for mu in space:
-            mu_idx, mu = self.add_mu(mu=mu, step=Stage.OFFLINE)
-            fom.setup()
-            fom.update_parametrization(mu)
-            fom.solve()
-            fom_solutions[mu_idx] = fom.solutions.fom.copy()
-            # time-level POD, normalised (rom.py:335)
-            basis_t, sig_t, en_t = orth(fom.solutions.snapshots, tol=tol_t)
-            per_mu.append(basis_t)
-            off[Treewalk.SPECTRUM_TIME][mu_idx] = sig_t
-            off[Treewalk.ENERGY_TIME][mu_idx] = en_t
-            off[Treewalk.BASIS_TIME][mu_idx] = basis_t.shape[1]
-            nl = getattr(fom, "nonlinear_snapshots", None)
-            if nl is not None and len(nl) > 1:
-                snaps = np.array(nl[1:]).T  # first one is zero (initial condition), rom.py:345
-                snaps[0, :] = 0.0
-                b_nl, s_nl, e_nl = orth(snaps, tol=tol_t)
-                per_mu_nl.append(b_nl)
-                off[TreewalkNonlinear.SPECTRUM_TIME][mu_idx] = s_nl
-                off[TreewalkNonlinear.ENERGY_TIME][mu_idx] = e_nl
-                off[TreewalkNonlinear.BASIS_TIME][mu_idx] = basis_t.shape[1]  # sic: rom.py:359-361
-            if getattr(fom, "RUNTIME_PROCESS", False) and hasattr(fom, "save_probes"):
-                fom.save_probes(name=f"probes_offline_fom_{mu_idx}.csv")
-        stacked = np.hstack(per_mu)
-        off[Treewalk.BASIS_AFTER_WALK] = stacked.shape[1]
-        basis, sig_mu, en_mu = orth(stacked, num=num_basis, tol=tol_mu, normalize=False)
-        off[Treewalk.SPECTRUM_MU] = sig_mu
+        fom_solutions = dict()
+        from . import walks
+
+        # The time-level PODs of all parameters (solution snapshots and, for the nonlinear problems, the snapshots of
+        # the state-dependent operator) are ONE sequence of independent PODs with the same truncation rule: every set is
+        # uploaded once when the FOM has produced it and goes through the device's POD lanes; the bases stay on the
+        # device for the mu-level PODs (walks.py).
+        tags = []
+
+        def time_level_sets():
+            for mu in space:
+                mu_idx, mu = self.add_mu(mu=mu, step=Stage.OFFLINE)
+                fom.setup()
+                fom.update_parametrization(mu)
+                fom.solve()
+                fom_solutions[mu_idx] = fom.solutions.fom.copy()
+                tags.append((mu_idx, False))
+                yield walks.upload(fom.solutions.snapshots)            # time-level POD, normalised (rom.py:335)
+                nl = getattr(fom, "nonlinear_snapshots", None)
+                if nl is not None and len(nl) > 1:
+                    snaps = np.array(nl[1:]).T  # first one is zero (initial condition), rom.py:345
+                    snaps[0, :] = 0.0
+                    tags.append((mu_idx, True))
+                    yield walks.upload(snaps)
+                if getattr(fom, "RUNTIME_PROCESS", False) and hasattr(fom, "save_probes"):
+                    fom.save_probes(name=f"probes_offline_fom_{mu_idx}.csv")
+
+        per_mu, per_mu_nl, width = [], [], dict()
+        for i, out in enumerate(walks.pod_sequence(time_level_sets(), tol=tol_t)):
+            mu_idx, nonlinear = tags[i]
+            if not nonlinear:
+                per_mu.append(out["Q"])
+                width[mu_idx] = out["Q"].shape[1]
+                off[Treewalk.SPECTRUM_TIME][mu_idx] = out["s"]
+                off[Treewalk.ENERGY_TIME][mu_idx] = out["energy"]
+                off[Treewalk.BASIS_TIME][mu_idx] = out["Q"].shape[1]
+            else:
+                per_mu_nl.append(out["Q"])
+                off[TreewalkNonlinear.SPECTRUM_TIME][mu_idx] = out["s"]
+                off[TreewalkNonlinear.ENERGY_TIME][mu_idx] = out["energy"]
+                off[TreewalkNonlinear.BASIS_TIME][mu_idx] = width[mu_idx]  # sic: rom.py:359-361
+        top = walks.pod_of_stack(per_mu, num=num_basis, tol=tol_mu, normalize=False)
+        en_mu = top["energy"]
+        off[Treewalk.BASIS_AFTER_WALK] = top["stacked_columns"]
+        off[Treewalk.SPECTRUM_MU] = top["s"]
         off[Treewalk.ENERGY_MU] = en_mu
-        off[Treewalk.BASIS_FINAL] = basis.shape[1]
-        self.basis = basis
+        off[Treewalk.BASIS_FINAL] = top["Q"].shape[1]
+        self.basis = top["Q"].cpu().numpy()
         if per_mu_nl:
-            stacked_nl = np.hstack(per_mu_nl)
-            off[TreewalkNonlinear.BASIS_AFTER_WALK] = stacked_nl.shape[1]
-            b_nl, s_nl, e_nl = orth(stacked_nl, normalize=False)
-            off[TreewalkNonlinear.SPECTRUM_MU] = s_nl
-            off[TreewalkNonlinear.ENERGY_MU] = e_nl
-            off[TreewalkNonlinear.BASIS_FINAL] = b_nl.shape[1]
-            self.basis_nonlinear = b_nl
+            top_nl = walks.pod_of_stack(per_mu_nl, normalize=False)
+            off[TreewalkNonlinear.BASIS_AFTER_WALK] = top_nl["stacked_columns"]
+            off[TreewalkNonlinear.SPECTRUM_MU] = top_nl["s"]
+            off[TreewalkNonlinear.ENERGY_MU] = top_nl["energy"]
+            off[TreewalkNonlinear.BASIS_FINAL] = top_nl["Q"].shape[1]
+            self.basis_nonlinear = top_nl["Q"].cpu().numpy()
         assert self.N != 0, (
             "(ROM) There are no basis vectors. \n See tolerance according to mu-energy: "
             f"{tolerances.get(RomParameters.TOL_MU)} < {en_mu}"

@@ -1,0 +1,73 @@
+"""Device-resident POD tree walks (rom/rom.py:317-406, deim/deim.py:279-397, deim/nonlinear.py:320-468).
+
+A tree walk is a SEQUENCE of independent small PODs (one per parameter at the time level, one per time step at the
+N-MDEIM basis level) followed by the POD of their concatenated bases.  The reference runs them one after the other on
+the host and ``np.hstack``s the bases.  Here
+
+  * every snapshot set is uploaded once, when its turn comes (the FOM callbacks that produce it stay on the host),
+  * the PODs of a level run through ``pipeline.PodLanes`` - eight chains on the chip at a time, one eigensolver team
+    per XCD, everything enqueued ahead of the spectrum; orth's truncation rule (``tol`` > ``num`` > 1e-7) is applied to
+    the spectrum afterwards, and a set whose spectrum needs deflated levels or a Rayleigh-Ritz step is recomputed on
+    the regular route (``pod.pod_device``), so the results are those of ``orth`` set by set,
+  * the bases never leave the device: the next level's snapshot matrix is ``torch.cat`` of them, and only the final
+    basis (the classes keep NumPy attributes, as the reference's pickles do) and the spectra of the reports come back.
+"""
+from __future__ import annotations
+
+import threading
+
+import torch
+
+from . import ops, pod
+
+_tls = threading.local()
+
+
+def _lanes(device):
+    from .pipeline import PodLanes
+
+    cache = getattr(_tls, "lanes", None)
+    if cache is None:
+        cache = _tls.lanes = {}
+    key = device.index
+    if key not in cache:
+        cache[key] = PodLanes(device=key)
+    return cache[key]
+
+
+def pod_sequence(snapshot_sets, num=None, tol=None, normalize=True, cap=64):
+    """Generator over ``pod.pod_device``-style results (``Q`` on the device, ``s`` / ``energy`` host arrays, ``r``) of
+    ``orth(X, num=num, tol=tol, normalize=normalize)`` for every X of ``snapshot_sets``, in order.  ``snapshot_sets``
+    may be lazy (each set produced - assembled on the host, uploaded - when asked for): up to eight are asked for
+    before the first result is handed out."""
+    it = iter(snapshot_sets)
+    try:
+        first = next(it)
+    except StopIteration:
+        return
+
+    def chain():
+        yield first
+        yield from it
+
+    if not first.is_cuda:
+        # only reachable with the operators replaced by host stand-ins (tests/cpu_stub.py: the host-logic tests);
+        # the real ``ops.to_device`` has produced a CUDA tensor or raised
+        for X in chain():
+            yield pod.pod_device(X, num=num, tol=tol, normalize=normalize)
+        return
+    yield from _lanes(first.device).run(chain(), num=num, tol=tol, normalize=normalize, cap=cap)
+
+
+def pod_of_stack(bases, num=None, tol=None, normalize=True):
+    """POD of the column-wise concatenation of device bases (the mu level / time level of a walk): the stacked matrix
+    is built on the device (``np.hstack`` in the reference, rom.py:368, deim.py:340) and never visits the host."""
+    stacked = torch.cat(list(bases), dim=1)
+    out = pod.pod_device(stacked, num=num, tol=tol, normalize=normalize)
+    out["stacked_columns"] = int(stacked.shape[1])
+    return out
+
+
+def upload(snapshots):
+    """Host snapshot matrix -> device, keeping its memory order (no host transpose)."""
+    return ops.to_device(snapshots)
