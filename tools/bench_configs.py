@@ -281,7 +281,68 @@ def c5h(nt=2000, n_mu=32, N=100_000, r=80, m_lin=40, m_nl=120, m_rhs=20):
                 rel_diff_vs_direct_device_sweep_first40=cross)
 
 
+def walk16(n_mu=16, N=100_000, n_t=256, num_t=40, num_mu=40):
+    """A DEIM tree walk through the class surface (deim.py:279-397): 16 parameters x (1e5 x 256) time-level snapshot
+    sets, 40 modes each, then the mu-level POD of the 1e5 x 640 concatenation - the device-resident walk (each set
+    uploaded once, time-level PODs through the POD lanes, bases concatenated on the device; walks.py) against the
+    reference's loop as round 2 ran it (one orth(ndarray) per parameter: upload, POD, download; np.hstack; orth again).
+    The FOM callback is a table lookup, so what is timed is the walk, not an assembly."""
+    from romtime_amd import DiscreteEmpiricalInterpolation
+    from romtime_amd.conventions import Stage
+
+    rng = np.random.RandomState(16)
+    sig = 10.0 ** (-6.0 * np.arange(n_t) / (n_t - 1))
+    V0, _ = np.linalg.qr(rng.standard_normal((n_t, n_t)))
+    tables = {}
+    for j in range(n_mu):                      # snapshot j of parameter i = row j of tables[i] (contiguous vectors)
+        Z = torch.randn((N, n_t), dtype=torch.float64, device="cuda") / np.sqrt(N)
+        tables[j] = (Z @ torch.from_numpy((sig * (1.0 + 0.05 * j))[:, None] * V0.T).cuda()).T.contiguous().cpu().numpy()
+    ts = list(range(n_t))
+    space = [dict(i=j) for j in range(n_mu)]
+    assemble = lambda mu, t: tables[mu["i"]][t]
+
+    def run(host_loop):
+        d = DiscreteEmpiricalInterpolation(assemble=assemble, name="walk16")
+        d.setup()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if host_loop:
+            basis, sig_mu = d._tree_walk_host(space, ts, False, num_mu, num_t, None, None)
+        else:
+            basis, sig_mu = d.tree_walk(ts=ts, normalize=False, num_mu=num_mu, num_t=num_t, mu_space=space)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, basis, sig_mu, d.report[Stage.OFFLINE]
+
+    run(False), run(True)                      # warm-up: lanes, arenas, pinned buffers
+    t_dev, B_dev, s_dev, rep_dev = run(False)
+    t_host, B_host, s_host, rep_host = run(True)
+    sub = np.linalg.norm(B_dev - B_host @ (B_host.T @ B_dev), 2)
+    # device-resident sets (no FOM, no PCIe): what the lanes and the on-device concatenation are worth by themselves
+    from romtime_amd import walks
+
+    dev_sets = [ops.to_device(tables[j].T) for j in range(n_mu)]
+
+    def lanes():
+        per = [o["Q"] for o in walks.pod_sequence(dev_sets, num=num_t, normalize=False)]
+        return walks.pod_of_stack(per, num=num_mu, normalize=False)
+
+    def one_by_one():
+        per = [pod.pod_device(X, num=num_t, normalize=False)["Q"] for X in dev_sets]
+        return pod.pod_device(torch.cat(per, dim=1), num=num_mu, normalize=False)
+
+    ms_lanes, _ = wall_time(lanes, reps=3)
+    ms_seq, _ = wall_time(one_by_one, reps=3)
+    return dict(config=f"tree walk, {n_mu} mu x ({N} x {n_t}), {num_t} modes per mu, {num_mu} final (DEIM class surface)",
+                device_walk_s=t_dev, host_loop_s=t_host, speedup=t_host / t_dev,
+                sigma_mu_rel_diff=float(np.abs(s_dev - s_host).max() / s_host[0]), subspace_dist=float(sub),
+                basis_after_walk=rep_dev["basis-shape-after-tree-walk"] if "basis-shape-after-tree-walk" in rep_dev else None,
+                device_resident_sets=dict(lanes_ms=ms_lanes, one_by_one_ms=ms_seq, speedup=ms_seq / ms_lanes),
+                note="host-resident snapshots: the walk is bound by the upload of each 205 MB set (pageable memory) and "
+                     "the host-side np.array(...).T of the FOM's vectors; the device walk removes the download of every "
+                     "time-level basis and the 512 MB re-upload of their concatenation")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["c2", "c2pipe", "c4", "c5", "c5sweep", "c5h"]
+    which = sys.argv[1:] or ["c2", "c2pipe", "walk16", "c4", "c5", "c5sweep", "c5h"]
     for w in which:
-        print(json.dumps({"c2": c2, "c2pipe": c2pipe, "c4": c4, "c5": c5, "c5sweep": c5sweep, "c5h": c5h}[w]()), flush=True)
+        print(json.dumps({"c2": c2, "c2pipe": c2pipe, "walk16": walk16, "c4": c4, "c5": c5, "c5sweep": c5sweep, "c5h": c5h}[w]()), flush=True)
