@@ -14,7 +14,20 @@
 //    DIAG instantiation (72 accumulator VGPRs instead of 128, A panel only), each launch with
 //    its own number of sub-splits so that it fills the chip evenly.
 //
-// Output: per-(XCD, slot) 128x128 slabs, summed in a fixed order by gram_reduce_kernel
+//
+//  * Round 3, an alternative kept behind ROMTIME_GRAM_FLAGS & 16 (it measured no faster, see rt_gram128): ONE launch.
+//    The two launches each sweep all of X (8.2 GB of HBM reads at best, 13 GB measured in the pipeline) and each leave
+//    slots of the chip idle (6 tiles do not divide 64 slots).  In the one-launch form every workgroup slot of an XCD
+//    carries up to two SEGMENTS - (tile, stage stride and offset, stage
+//    range of the XCD's K range) - run one after the other with the accumulators flushed to a slab in between:
+//      - an off-diagonal tile gets S_off slots that take its stages q, q + S_off, ... over the whole range;
+//      - a diagonal tile (36 of 64 MFMA tiles: cheaper per stage, but 6 S_off + 4 S_diag = slots has no solution with
+//        equal time per slot) gets s_d dedicated slots for the first phi of the range, and its LAST (1 - phi) is dealt
+//        to off-diagonal slots as their second segment - they reach the end of the K range at the same time as the
+//        dedicated slots get there, so every panel is still read from HBM once per XCD and shared through the L2
+//        by all tiles that need it, and all slots finish together (gram_plan()).
+//
+// Output: per-(XCD, segment) 128x128 slabs, summed in a fixed order by gram_reduce_kernel
 // (bitwise reproducible; exactly symmetric G).
 #include <cstdlib>
 #include <type_traits>
@@ -40,6 +53,14 @@ struct GramParams {
   unsigned char slot_tm[MAX_SLOTS], slot_tn[MAX_SLOTS], slot_q[MAX_SLOTS], slot_S[MAX_SLOTS];
 };
 
+// One launch (gram128_merged_kernel): up to two segments per slot.  S == 0: no such segment.  Stage indices are local
+// to the XCD's K range; a segment takes stages s0 + q, s0 + q + S, ... below s1.
+struct GramSegs {
+  unsigned char tm[2][MAX_SLOTS], tn[2][MAX_SLOTS], q[2][MAX_SLOTS], S[2][MAX_SLOTS];
+  unsigned short slab[2][MAX_SLOTS];
+  int s0[2][MAX_SLOTS], s1[2][MAX_SLOTS];
+};
+
 // MFMA-tile sets of a diagonal 128x128 tile (8x8 grid of 16x16 tiles, only i <= j: 36 tiles): waves 0-3 take five
 // consecutive tiles of the row-wise list each, waves 4-7 four.  Waves w and w + 4 of a workgroup share a SIMD, so
 // every SIMD issues 9 MFMAs per k-step (5,5,5,5,5,5,4,2 put 10 on two of them: 10 % of the kernel).
@@ -48,31 +69,29 @@ struct GramParams {
 __device__ const unsigned char kDiagTi[8][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 1, 1}, {1, 1, 1, 1, 1}, {2, 2, 2, 2, 2}, {2, 3, 3, 3, 255}, {3, 3, 4, 4, 255}, {4, 4, 5, 5, 255}, {5, 6, 6, 7, 255}};
 __device__ const unsigned char kDiagTj[8][5] = {{0, 1, 2, 3, 4}, {5, 6, 7, 1, 2}, {3, 4, 5, 6, 7}, {2, 3, 4, 5, 6}, {7, 3, 4, 5, 0}, {6, 7, 4, 5, 0}, {6, 7, 5, 6, 0}, {7, 6, 7, 7, 0}};
 
+// One segment: the 128 x 128 tile (tm, tn) of X^T X over the stages s0 + q0, s0 + q0 + S, ... (< s1, < the end of XCD
+// x's K range) of XCD x's rows, written to `out` (a 128 x 128 slab).  All arguments are wave-uniform (SGPRs).
 template <bool KC, bool DIAG>
-__global__ __launch_bounds__(GT, 4) void gram128_kernel(const GramParams p) {
+__device__ __forceinline__ void gram_segment(const GramParams& p, double* smem, int x, int tm, int tn, int q0, int S,
+                                             int s0, int s1, double* out) {
   using P = Panel<BT, KC, GT>;
-  extern __shared__ __attribute__((aligned(16))) double smem[];
   double* sA0 = smem;
   double* sA1 = smem + P::LDS;
   double* sB0 = smem + 2 * P::LDS;
   double* sB1 = smem + 3 * P::LDS;
 
-  const int tid = threadIdx.x;
-  const int x = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  // the XCD-local K ranges rest on workgroup i running on XCD i % 8: count the ones that do not (rt_ctx_get_counter
-  // "gram_off_xcd"; a CU-masked stream or a driver change could break the rule, the L2 reuse would go with it)
-  if (tid == 0 && (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) != x)
-    atomicAdd(reinterpret_cast<unsigned long long*>(&p.counters[RT_CNT_GRAM_OFF_XCD]), 1ull);
-  // (a byte table in the kernel arguments indexed by a run-time slot is fetched with VECTOR loads: without the
-  // readfirstlane every quantity derived from these four - tile origin, K range, panel pointers - lives in VGPRs and
-  // all the "uniform" arithmetic of the loop is VALU work, which FP64 MFMAs cannot overlap with)
-  const int tm = __builtin_amdgcn_readfirstlane((int)p.slot_tm[slot]), tn = __builtin_amdgcn_readfirstlane((int)p.slot_tn[slot]),
-            q0 = __builtin_amdgcn_readfirstlane((int)p.slot_q[slot]), S = __builtin_amdgcn_readfirstlane((int)p.slot_S[slot]);
+  // opaque to the optimiser: nothing derived from the thread index is carried from one segment of the merged kernel
+  // into the next (the off-diagonal loop has no VGPR to spare: values kept alive across segments were spilled in it)
+  int tid = threadIdx.x;
+  asm volatile("" : "+v"(tid));
   const long m0 = (long)tm * BT, n0 = (long)tn * BT;
+  const long kend_x = ((long)x * p.kx + p.kx < p.K) ? (long)x * p.kx + p.kx : p.K;
+  const int nst_x = (kend_x > (long)x * p.kx) ? (int)((kend_x - (long)x * p.kx + KB - 1) / KB) : 0;
+  const int send = s1 < nst_x ? s1 : nst_x;
+  q0 += s0;                                                            // first stage of the segment
   const long kbeg = (long)x * p.kx;
-  const long kend = (kbeg + p.kx < p.K) ? kbeg + p.kx : p.K;
-  const int nst_all = (kend > kbeg) ? (int)((kend - kbeg + KB - 1) / KB) : 0;
-  const int nstages = (nst_all > q0) ? (nst_all - q0 + S - 1) / S : 0;  // stages q0, q0+S, ...
+  const long kend = kend_x;
+  const int nstages = (send > q0) ? (send - q0 + S - 1) / S : 0;      // stages q0, q0+S, ...
 
   const int lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 2, wn = wid & 3;
@@ -202,7 +221,6 @@ __global__ __launch_bounds__(GT, 4) void gram128_kernel(const GramParams p) {
     __syncthreads();
   }
 
-  double* out = p.slab + ((long)x * p.nslots + slot) * (BT * BT);
   if constexpr (DIAG) {
 #pragma unroll
     for (int q = 0; q < 5; ++q)
@@ -217,6 +235,49 @@ __global__ __launch_bounds__(GT, 4) void gram128_kernel(const GramParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
           out[(wm * 64 + i * 16 + l4 + 4 * r) * BT + wn * 32 + j * 16 + l15] = acc[i * 2 + j][r];
+  }
+}
+
+// the XCD-local K ranges rest on workgroup i running on XCD i % 8: count the ones that do not (rt_ctx_get_counter
+// "gram_off_xcd"; a CU-masked stream or a driver change could break the rule, the L2 reuse would go with it)
+__device__ __forceinline__ void gram_check_xcd(const GramParams& p, int x) {
+  if (threadIdx.x == 0 && (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & 15u) != x)
+    atomicAdd(reinterpret_cast<unsigned long long*>(&p.counters[RT_CNT_GRAM_OFF_XCD]), 1ull);
+}
+
+// Two launches (short snapshot sets, where the plan of the merged kernel does not apply): one tile kind per launch.
+template <bool KC, bool DIAG>
+__global__ __launch_bounds__(GT, 4) void gram128_kernel(const GramParams p) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int x = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  gram_check_xcd(p, x);
+  // (a byte table in the kernel arguments indexed by a run-time slot is fetched with VECTOR loads: without the
+  // readfirstlane every quantity derived from these four - tile origin, K range, panel pointers - lives in VGPRs and
+  // all the "uniform" arithmetic of the loop is VALU work, which FP64 MFMAs cannot overlap with)
+  const int tm = __builtin_amdgcn_readfirstlane((int)p.slot_tm[slot]), tn = __builtin_amdgcn_readfirstlane((int)p.slot_tn[slot]),
+            q0 = __builtin_amdgcn_readfirstlane((int)p.slot_q[slot]), S = __builtin_amdgcn_readfirstlane((int)p.slot_S[slot]);
+  gram_segment<KC, DIAG>(p, smem, x, tm, tn, q0, S, 0, 0x7fffffff, p.slab + ((long)x * p.nslots + slot) * (BT * BT));
+}
+
+// One launch: every slot runs its (up to) two segments, off-diagonal or diagonal as the plan says (gram_plan()).
+template <bool KC>
+__global__ __launch_bounds__(GT, 4) void gram128_merged_kernel(const GramParams p, const GramSegs g) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const int x = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  gram_check_xcd(p, x);
+#pragma unroll 1
+  for (int sg = 0; sg < 2; ++sg) {
+    const int S = __builtin_amdgcn_readfirstlane((int)g.S[sg][slot]);
+    if (S == 0) continue;
+    const int tm = __builtin_amdgcn_readfirstlane((int)g.tm[sg][slot]), tn = __builtin_amdgcn_readfirstlane((int)g.tn[sg][slot]),
+              q0 = __builtin_amdgcn_readfirstlane((int)g.q[sg][slot]), s0 = __builtin_amdgcn_readfirstlane(g.s0[sg][slot]),
+              s1 = __builtin_amdgcn_readfirstlane(g.s1[sg][slot]), slab = __builtin_amdgcn_readfirstlane((int)g.slab[sg][slot]);
+    double* out = p.slab + ((long)x * p.nslots + slab) * (BT * BT);
+    if (tm == tn)
+      gram_segment<KC, true>(p, smem, x, tm, tn, q0, S, s0, s1, out);
+    else
+      gram_segment<KC, false>(p, smem, x, tm, tn, q0, S, s0, s1, out);
+    __syncthreads();   // the next segment reuses the LDS panels
   }
 }
 
@@ -263,6 +324,107 @@ int launch_gram(rt_ctx* ctx, const GramParams& p, int grid) {
   return RT_OK;
 }
 
+// The plan of the one-launch kernel: P slots per XCD, tiles1 x tiles1 tile grid (upper triangle), nst stages in an
+// XCD's K range, rho = cost of a diagonal-tile stage relative to an off-diagonal one (36 of 64 MFMA tiles, one panel
+// instead of two: 0.60 measured from the two-launch kernels' rates).  Equal time per slot:
+//   T* = (n_off + rho n_d) / P  per stage of the range;  S_off = ceil(1 / T*) slots per off-diagonal tile leave each of
+//   them T* - 1/S_off to spare; the other slots are dealt to the diagonal tiles (s_d each, differing by at most one);
+//   a diagonal tile that needs more than s_d T* gets H off-diagonal slots as helpers for the last 1 - phi of the range,
+//   phi from  phi rho / s_d = 1 / S_off + (1 - phi) rho / H  (dedicated slots and helpers finish together).
+// Fills the segments, the slab index of every segment and the per-tile slab lists of the reduction.
+bool gram_plan(int P, int tiles1, int nst, double rho, GramSegs& g, unsigned char* first, unsigned char* count, int* nslabs,
+               int* s_off_out) {
+  const int n_d = tiles1, n_off = tiles1 * (tiles1 - 1) / 2;
+  if (n_off < 1 || P > MAX_SLOTS) return false;
+  const double W = n_off + rho * n_d, Tstar = W / P;
+  int S_off = (int)(1.0 / Tstar - 1e-9) + 1;
+  while (S_off >= 1 && n_off * S_off + n_d > P) --S_off;
+  if (S_off < 1 || nst < 48 * S_off) return false;   // short sets: the two-launch form with its own caps
+  const int rem = P - n_off * S_off;
+  int s_d[8], H[8] = {0}, n1[8];
+  double need[8], total_need = 0.0;
+  const double spare = Tstar - 1.0 / S_off;
+  for (int i = 0; i < n_d; ++i) {
+    s_d[i] = rem / n_d + (i < rem % n_d ? 1 : 0);
+    need[i] = rho - s_d[i] * Tstar;
+    if (need[i] < 1e-3 * rho || spare <= 1e-3 * Tstar) need[i] = 0.0;
+    total_need += need[i];
+  }
+  int helpers_left = n_off * S_off;
+  for (int i = 0; i < n_d; ++i) {
+    n1[i] = 0x7fffffff;
+    if (need[i] <= 0.0) continue;
+    int h = (int)(n_off * S_off * need[i] / total_need);
+    if (h > helpers_left) h = helpers_left;
+    if (h > 255) h = 255;
+    if (h < 1) continue;
+    H[i] = h;
+    helpers_left -= h;
+    double phi = (1.0 / S_off + rho / h) / (rho / s_d[i] + rho / h);
+    if (phi > 1.0) phi = 1.0;
+    n1[i] = (int)(phi * nst + 0.5);
+    if (n1[i] >= nst) { n1[i] = 0x7fffffff; helpers_left += h; H[i] = 0; }
+  }
+  for (int sg = 0; sg < 2; ++sg)
+    for (int q = 0; q < MAX_SLOTS; ++q) {
+      g.tm[sg][q] = g.tn[sg][q] = g.q[sg][q] = g.S[sg][q] = 0;
+      g.slab[sg][q] = 0;
+      g.s0[sg][q] = 0;
+      g.s1[sg][q] = 0x7fffffff;
+    }
+  // off-diagonal tiles: slot = slab = tile-major index
+  int slot = 0, slab = 0, t = 0, off_index[MAX_TILES];
+  for (int a = 0; a < tiles1; ++a)
+    for (int b = a; b < tiles1; ++b, ++t) {
+      if (a == b) continue;
+      first[t] = (unsigned char)slab;
+      count[t] = (unsigned char)S_off;
+      for (int q = 0; q < S_off; ++q, ++slot, ++slab) {
+        g.tm[0][slot] = (unsigned char)a; g.tn[0][slot] = (unsigned char)b;
+        g.q[0][slot] = (unsigned char)q; g.S[0][slot] = (unsigned char)S_off;
+        g.slab[0][slot] = (unsigned short)slab;
+      }
+    }
+  (void)off_index;
+  // diagonal tiles: dedicated slots, then helpers (second segment of off-diagonal slots, taken in slot order so that
+  // the helpers of one diagonal tile are spread over several off-diagonal tiles)
+  int next_helper = 0;
+  t = 0;
+  for (int a = 0; a < tiles1; ++a)
+    for (int b = a; b < tiles1; ++b, ++t) {
+      if (a != b) continue;
+      first[t] = (unsigned char)slab;
+      count[t] = (unsigned char)(s_d[a] + H[a]);
+      for (int q = 0; q < s_d[a]; ++q, ++slot, ++slab) {
+        g.tm[0][slot] = g.tn[0][slot] = (unsigned char)a;
+        g.q[0][slot] = (unsigned char)q; g.S[0][slot] = (unsigned char)s_d[a];
+        g.s1[0][slot] = n1[a];
+        g.slab[0][slot] = (unsigned short)slab;
+      }
+      for (int h = 0; h < H[a]; ++h, ++slab) {
+        // helper slots: stride n_d through the off-diagonal slots, so consecutive helpers of a tile belong to different tiles
+        const int hs = next_helper++;
+        g.tm[1][hs] = g.tn[1][hs] = (unsigned char)a;
+        g.q[1][hs] = (unsigned char)h; g.S[1][hs] = (unsigned char)H[a];
+        g.s0[1][hs] = n1[a];
+        g.slab[1][hs] = (unsigned short)slab;
+      }
+    }
+  if (slab > 255) return false;
+  *nslabs = slab;
+  *s_off_out = S_off;
+  return slot == P;
+}
+
+template <bool KC>
+int launch_gram_merged(rt_ctx* ctx, const GramParams& p, const GramSegs& g, int grid) {
+  constexpr size_t lds = sizeof(double) * 4 * Panel<BT, KC, GT>::LDS;
+  RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&gram128_merged_kernel<KC>), (int)lds));
+  hipLaunchKernelGGL((gram128_merged_kernel<KC>), dim3(grid), dim3(GT), lds, ctx->stream, p, g);
+  RT_HIP_CHECK(ctx, hipGetLastError());
+  return RT_OK;
+}
+
 }  // namespace
 
 // Returns RT_ERR_UNSUPPORTED when the shape is outside this kernel's regime (caller falls back to
@@ -289,6 +451,52 @@ int rt_gram128(rt_ctx* ctx, const double* X, int64_t ks, int64_t ms, int64_t K, 
   p.flags = env_flags;
   p.counters = ctx->dev_counters;
 
+  // ---- one launch (ROMTIME_GRAM_FLAGS & 16; long snapshot sets with off-diagonal tiles) --------------------------------
+  // Measured (tools/probes/gram_merged_ab.sh, profiles/r03_gram_merged_ab.txt): perfectly balanced slots and one launch
+  // buy nothing - 4.36 vs 4.34 ms back to back on the whole chip, 4.80 vs 4.66 ms inside the POD pipeline (224 CUs), HBM
+  // reads 12.9 vs 13.6 GB.  The kernel runs at the board's power limit: the slots the two-launch form leaves idle (4 of
+  // 64 in the off-diagonal launch) are not lost time, the busy ones clock higher.  Kept as a switch, not the default.
+  static const int rho_pct = [] { const char* e = getenv("ROMTIME_GRAM_RHO"); return e ? atoi(e) : 60; }();
+  if ((env_flags & 16) && n_off >= 1) {
+    GramSegs g;
+    GramReduceParams rp;
+    int nslabs = 0, s_off = 0;
+    if (gram_plan(slots_max, tiles1, (int)(p.kx / KB), rho_pct / 100.0, g, rp.first, rp.count, &nslabs, &s_off)) {
+      void* slab = nullptr;
+      int rc = rt_scratch(ctx, sizeof(double) * BT * BT * 8 * (size_t)nslabs, &slab);
+      if (rc != RT_OK) return rc;
+      p.slab = static_cast<double*>(slab); p.nslots = nslabs;
+      rp.slab_off = rp.slab_diag = p.slab; rp.G = G; rp.n = n;
+      rp.nslots_off = rp.nslots_diag = nslabs; rp.tiles1 = tiles1;
+      if (ctx->profile) {
+        if (!ctx->ev0) {
+          RT_HIP_CHECK(ctx, hipEventCreate(&ctx->ev0));
+          RT_HIP_CHECK(ctx, hipEventCreate(&ctx->ev1));
+        }
+        if (!ctx->gev0) {
+          RT_HIP_CHECK(ctx, hipEventCreate(&ctx->gev0));
+          RT_HIP_CHECK(ctx, hipEventCreate(&ctx->gev1));
+        }
+        RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+        RT_HIP_CHECK(ctx, hipEventRecord(ctx->gev0, ctx->stream));
+      }
+      rc = kc ? launch_gram_merged<true>(ctx, p, g, 8 * slots_max) : launch_gram_merged<false>(ctx, p, g, 8 * slots_max);
+      if (rc != RT_OK) return rc;
+      if (ctx->profile) {
+        RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+        RT_HIP_CHECK(ctx, hipEventRecord(ctx->gev1, ctx->stream));
+        ctx->ev_valid = true;
+        ctx->gev_valid = true;
+      }
+      ctx->last_grid = 8 * slots_max; ctx->last_splits = 8 * s_off; ctx->last_tile = 128 * 1000 + 128;
+      const long total = n * n;
+      hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, rp);
+      RT_HIP_CHECK(ctx, hipGetLastError());
+      return RT_OK;
+    }
+  }
+
+  // ---- two launches (the default) -------------------------------------------------------------------------------------
   int S_off = n_off ? slots_max / n_off : 0;   // sub-splits per off-diagonal tile per XCD
   int S_diag = slots_max / tiles1;             // ... per diagonal tile
   // Shorter snapshot sets get fewer sub-splits, at least 48 stages each (below that the slab traffic and the two

@@ -183,6 +183,114 @@ __global__ __launch_bounds__(TS_THREADS, RB == 2 ? (NT <= 4 ? 3 : 1) : (NT <= 4 
       }
 }
 
+// Round 3: X never touches LDS.  The contraction index of an MFMA is a dummy: lane (l15, l4) of a 16x16x4 step may
+// supply ANY k as long as the B operand of the same lane supplies the same one.  So a lane loads four CONSECUTIVE
+// doubles of "its" row (one 32-byte load; the four l4 groups of a row together read 128 contiguous bytes) and feeds them
+// to four successive MFMA steps, while the B operand is read from the T stage in LDS at row 16 jb + 4 l4 + step instead
+// of 4 step + l4.  Against the staged kernel a stage of 32 columns loses 8 ds_write_b128 and 16 ds_read_b64 per thread
+// (X never goes through LDS), their address arithmetic - all of it VALU work that an FP64 MFMA cannot overlap with - and
+// one of the two barriers (the T stages are double buffered; T is the only thing the waves of a workgroup share).
+template <int NT, int RB>
+__global__ __launch_bounds__(TS_THREADS, RB == 2 ? (NT <= 4 ? 3 : 1) : (NT <= 4 ? 4 : 2)) void tallskinny_direct_kernel(const TsParams p) {
+  constexpr int TS_BM = 64 * RB;
+  constexpr int KP = 16 * NT;                                 // padded output width
+  constexpr int TL = (TS_KS * KP / 2 + TS_THREADS - 1) / TS_THREADS;  // d2 loads of T per thread and stage
+  constexpr int JB = TS_KS / 16;                              // 16-column blocks of a stage: one d4 load each
+  __shared__ __attribute__((aligned(16))) double sT[2][TS_KS * KP];
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long row0 = (long)blockIdx.x * TS_BM;
+
+  d4 acc[RB][NT];
+#pragma unroll
+  for (int b = 0; b < RB; ++b)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[b][j] = d4{0.0, 0.0, 0.0, 0.0};
+
+  // per-thread byte offsets, computed once; stage bases are wave-uniform and advance by scalar adds
+  unsigned xoff[RB];
+#pragma unroll
+  for (int b = 0; b < RB; ++b) xoff[b] = (unsigned)(((long)(64 * b + 16 * wid + l15) * p.ldx + 4 * l4) * 8);
+  unsigned toff[TL];
+  bool tuse[TL];
+  d2 tr[TL];
+#pragma unroll
+  for (int i = 0; i < TL; ++i) {
+    const int q = tid + TS_THREADS * i, kk = q / (KP / 2), j = 2 * (q % (KP / 2));
+    toff[i] = (unsigned)(((long)kk * p.ldt + j) * 8);
+    tuse[i] = (kk < TS_KS) && (j + 1 < p.k);                                        // padded columns stay zero
+    tr[i] = d2{0.0, 0.0};
+  }
+  const char* gx = reinterpret_cast<const char*>(p.X + row0 * p.ldx);
+  const char* gt = reinterpret_cast<const char*>(p.T);
+  const long tstage = (long)TS_KS * p.ldt * 8;
+  auto commit = [&](double* dst) {
+#pragma unroll
+    for (int i = 0; i < TL; ++i) {
+      const int q = tid + TS_THREADS * i, kk = q / (KP / 2), j = 2 * (q % (KP / 2));
+      if (kk < TS_KS) *reinterpret_cast<d2*>(&dst[kk * KP + j]) = tr[i];
+    }
+  };
+  d4 xa[RB][JB], xn[RB][JB];
+  // stage 0
+#pragma unroll
+  for (int i = 0; i < TL; ++i)
+    if (tuse[i]) tr[i] = *reinterpret_cast<const d2*>(gt + toff[i]);
+#pragma unroll
+  for (int b = 0; b < RB; ++b)
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb) xa[b][jb] = *reinterpret_cast<const d4*>(gx + xoff[b] + jb * 128);
+  commit(sT[0]);
+  __syncthreads();
+  const int nstage = p.n / TS_KS;
+  const double* fb0 = sT[0] + 4 * l4 * KP + l15;   // B operand of step st of block jb: row 16 jb + 4 l4 + st, column 16 j + l15
+  for (int s = 0; s < nstage; ++s) {
+    const bool more = s + 1 < nstage;
+    if (more) {
+      gx += TS_KS * 8;
+      gt += tstage;
+#pragma unroll
+      for (int b = 0; b < RB; ++b)
+#pragma unroll
+        for (int jb = 0; jb < JB; ++jb) xn[b][jb] = *reinterpret_cast<const d4*>(gx + xoff[b] + jb * 128);
+#pragma unroll
+      for (int i = 0; i < TL; ++i)
+        if (tuse[i]) tr[i] = *reinterpret_cast<const d2*>(gt + toff[i]);
+    }
+    const double* fb = fb0 + (s & 1) * (TS_KS * KP);
+#pragma unroll
+    for (int jb = 0; jb < JB; ++jb)
+#pragma unroll
+      for (int st = 0; st < 4; ++st) {
+        double bq[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bq[j] = fb[(16 * jb + st) * KP + 16 * j];
+#pragma unroll
+        for (int b = 0; b < RB; ++b)
+#pragma unroll
+          for (int j = 0; j < NT; ++j) acc[b][j] = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[b][jb][st], bq[j], acc[b][j], 0, 0, 0);
+      }
+    if (more) {
+      commit(sT[(s + 1) & 1]);   // the other buffer: everybody left it at the barrier that ended stage s - 1
+#pragma unroll
+      for (int b = 0; b < RB; ++b)
+#pragma unroll
+        for (int jb = 0; jb < JB; ++jb) xa[b][jb] = xn[b][jb];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int b = 0; b < RB; ++b)
+#pragma unroll
+    for (int j = 0; j < NT; ++j)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const long row = row0 + 64 * b + 16 * wid + l4 + 4 * c;
+        const int col = 16 * j + l15;
+        if (col < p.k) p.Y[row * p.ldy + col] = acc[b][j][c];
+      }
+}
+
 }  // namespace
 
 // RT_ERR_UNSUPPORTED: shape outside this kernel's range (the caller uses the generic GEMM).
@@ -203,8 +311,22 @@ int rt_tallskinny(rt_ctx* ctx, const double* X, int64_t ldx, const double* T, in
     }
     RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   }
+  // the direct form needs whole workgroups, whole stages and 32-byte aligned row segments; one partial workgroup at the
+  // end of X goes through the staged kernel in a launch of its own
+  const bool direct = !(ts_flags & 4) && rb == 2 && (n % TS_KS == 0) && ((k & 1) == 0) && (ldx % 4 == 0) && (ldt % 2 == 0) &&
+                      ((reinterpret_cast<size_t>(X) & 31) == 0) && ((reinterpret_cast<size_t>(T) & 15) == 0) &&
+                      ((long)bm * ldx * 8 < (1L << 31)) && ((long)TS_KS * ldt * 8 < (1L << 31));
+  const unsigned grid_direct = direct ? (unsigned)(N / bm) : 0u;
+  TsParams ptail = p;
+  if (direct) {
+    const long done = (long)grid_direct * bm;
+    ptail.X = X + done * ldx; ptail.Y = Y + done * ldy; ptail.N = N - done;
+  }
 #define TS_LAUNCH(NT_)                                                                                                  \
-  if (rb == 2) hipLaunchKernelGGL((tallskinny_kernel<(NT_ <= 4 ? NT_ : 4), 2>), dim3(grid), dim3(TS_THREADS), 0, ctx->stream, p); \
+  if (direct) {                                                                                                         \
+    hipLaunchKernelGGL((tallskinny_direct_kernel<(NT_ <= 4 ? NT_ : 4), 2>), dim3(grid_direct), dim3(TS_THREADS), 0, ctx->stream, p); \
+    if (ptail.N > 0) hipLaunchKernelGGL((tallskinny_kernel<(NT_ <= 4 ? NT_ : 4), 2>), dim3(1), dim3(TS_THREADS), 0, ctx->stream, ptail); \
+  } else if (rb == 2) hipLaunchKernelGGL((tallskinny_kernel<(NT_ <= 4 ? NT_ : 4), 2>), dim3(grid), dim3(TS_THREADS), 0, ctx->stream, p); \
   else hipLaunchKernelGGL((tallskinny_kernel<NT_, 1>), dim3(grid), dim3(TS_THREADS), 0, ctx->stream, p)
   switch (nt) {
     case 1: TS_LAUNCH(1); break;
