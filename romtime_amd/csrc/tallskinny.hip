@@ -29,6 +29,7 @@ struct TsParams {
   long N, ldx, ldt, ldy;
   int n, k;
   int no_fast;   // ROMTIME_TS_FLAGS & 1: measurement switch, general refill path only
+  int nt_x, nt_y;  // ROMTIME_TS_FLAGS & 8 / & 16: non-temporal loads of X / stores of Y (measurement switches)
 };
 
 // RB = 16-row blocks per wave: a workgroup takes 64 RB rows.  With RB = 2 a T stage (re-read from L2 by every workgroup)
@@ -129,7 +130,10 @@ __global__ __launch_bounds__(TS_THREADS, RB == 2 ? (NT <= 4 ? 3 : 1) : (NT <= 4 
     const long tstage = (long)TS_KS * p.ldt * 8;
     for (; c0 + TS_KS < p.n; c0 += TS_KS) {
 #pragma unroll
-      for (int i = 0; i < TS_XL; ++i) xr[i] = *reinterpret_cast<const d2*>(gx + i * xstep + xoff);
+      for (int i = 0; i < TS_XL; ++i) {
+        const d2* src = reinterpret_cast<const d2*>(gx + i * xstep + xoff);
+        xr[i] = p.nt_x ? __builtin_nontemporal_load(src) : *src;
+      }
 #pragma unroll
       for (int i = 0; i < TL; ++i)
         if (tuse[i]) tr[i] = *reinterpret_cast<const d2*>(gt + toff[i]);
@@ -179,11 +183,16 @@ __global__ __launch_bounds__(TS_THREADS, RB == 2 ? (NT <= 4 ? 3 : 1) : (NT <= 4 
       for (int c = 0; c < 4; ++c) {
         const long row = row0 + 64 * b + 16 * wid + l4 + 4 * c;
         const int col = 16 * j + l15;
-        if (row < p.N && col < p.k) p.Y[row * p.ldy + col] = acc[b][j][c];
+        if (row < p.N && col < p.k) {
+          if (p.nt_y) __builtin_nontemporal_store(acc[b][j][c], &p.Y[row * p.ldy + col]);
+          else p.Y[row * p.ldy + col] = acc[b][j][c];
+        }
       }
 }
 
-// Round 3: X never touches LDS.  The contraction index of an MFMA is a dummy: lane (l15, l4) of a 16x16x4 step may
+// Round 3, an alternative kept behind ROMTIME_TS_FLAGS & 4 - it measured SLOWER than the staged kernel (1.095 vs 1.04 ms at
+// 1e6 x 512 -> 40, tools/probes/ts_ab.py, profiles/r03_tallskinny_ab.txt; non-temporal loads of X / stores of Y change
+// nothing either: 1.03-1.04 ms): X never touches LDS.  The contraction index of an MFMA is a dummy: lane (l15, l4) of a 16x16x4 step may
 // supply ANY k as long as the B operand of the same lane supplies the same one.  So a lane loads four CONSECUTIVE
 // doubles of "its" row (one 32-byte load; the four l4 groups of a row together read 128 contiguous bytes) and feeds them
 // to four successive MFMA steps, while the B operand is read from the T stage in LDS at row 16 jb + 4 l4 + step instead
@@ -298,7 +307,7 @@ int rt_tallskinny(rt_ctx* ctx, const double* X, int64_t ldx, const double* T, in
                   int64_t k, double* Y, int64_t ldy) {
   if (k > 128 || n < 2 * TS_KS || N < 64L * ctx->num_cus) return RT_ERR_UNSUPPORTED;
   static const int ts_flags = [] { const char* e = getenv("ROMTIME_TS_FLAGS"); return e ? atoi(e) : 0; }();
-  TsParams p{X, T, Y, (long)N, (long)ldx, (long)ldt, (long)ldy, (int)n, (int)k, ts_flags & 1};
+  TsParams p{X, T, Y, (long)N, (long)ldx, (long)ldt, (long)ldy, (int)n, (int)k, ts_flags & 1, (ts_flags >> 3) & 1, (ts_flags >> 4) & 1};
   const int nt = (int)((k + 15) / 16);
   // two 16-row blocks per wave when the 128-row workgroups still fill the chip a few times over and the accumulators fit
   const int rb = (nt <= 4 && !(ts_flags & 2) && N >= 128L * 4 * ctx->num_cus) ? 2 : 1;
@@ -313,7 +322,7 @@ int rt_tallskinny(rt_ctx* ctx, const double* X, int64_t ldx, const double* T, in
   }
   // the direct form needs whole workgroups, whole stages and 32-byte aligned row segments; one partial workgroup at the
   // end of X goes through the staged kernel in a launch of its own
-  const bool direct = !(ts_flags & 4) && rb == 2 && (n % TS_KS == 0) && ((k & 1) == 0) && (ldx % 4 == 0) && (ldt % 2 == 0) &&
+  const bool direct = (ts_flags & 4) && rb == 2 && (n % TS_KS == 0) && ((k & 1) == 0) && (ldx % 4 == 0) && (ldt % 2 == 0) &&
                       ((reinterpret_cast<size_t>(X) & 31) == 0) && ((reinterpret_cast<size_t>(T) & 15) == 0) &&
                       ((long)bm * ldx * 8 < (1L << 31)) && ((long)TS_KS * ldt * 8 < (1L << 31));
   const unsigned grid_direct = direct ? (unsigned)(N / bm) : 0u;

@@ -16,6 +16,6 @@ ref = X[:4096] @ T
 print("flags", os.environ.get("ROMTIME_TS_FLAGS", "0"), "ms", e0.elapsed_time(e1) / 30, "err", float((Y[:4096] - ref).abs().max()))
 ''' % __file__
 for rep in range(2):
-    for flags in ("2", "0"):
+    for flags in ("0", "4", "8", "16", "24"):   # 0 = staged kernel, 4 = direct-operand kernel, 8 = non-temporal X loads, 16 = non-temporal Y stores
         out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, ROMTIME_TS_FLAGS=flags), capture_output=True, text=True)
         print(out.stdout.strip() or out.stderr[-300:], flush=True)
