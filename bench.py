@@ -176,7 +176,7 @@ def secondary_online_sweep(ctx, device, nt, n_mu, r, n_h, with_cpu):
                    "ms_per_step_all_mu": 1e3 * wall_direct / nt, "solves": stats_direct},
         "hyper_reduced": {"value": nt * n_mu / wall_h, "unit": "reduced timesteps/s", "wall_s": wall_h,
                           "ms_per_step_all_mu": 1e3 * wall_h / nt, "solves": stats_h,
-                          "rel_l2_vs_direct_path": agree, "bound": "latency (2 dependent launches per step: expansion GEMM 16 us, tracked solve 36 us, ~4 us between them)"},
+                          "rel_l2_vs_direct_path": agree, "bound": "latency (2 dependent launches per step: expansion GEMM ~16 us, solve kernel ~22 us - the carried inverse used as a preconditioner of a few refinement steps, refreshed by Newton-Schulz only when they stop contracting fast: see solves.newton_iterations - and ~5 us between them)"},
         "roofline": dict(bound="mfma", achieved=achieved, peak=FP64_MFMA_PEAK_TFLOPS, unit="TFLOP/s",
                          frac=achieved / FP64_MFMA_PEAK_TFLOPS, traffic=proj_traffic, traffic_source=proj_traffic_source,
                          kernel="project_fused_kernel<5,false> (V^T(A_b V) for the n_mu operators of one step; the event pair also covers the <5,true> launch, which returns at once for a banded pattern)", kernel_ms=k_ms,

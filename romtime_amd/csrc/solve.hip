@@ -156,6 +156,10 @@ __global__ __launch_bounds__(SOLVE_THREADS) void dense_solve_kernel(const double
 // restarts from X = K^T / (||K||_1 ||K||_inf), which always converges for a nonsingular K.
 constexpr int NS_THREADS = 512;
 constexpr int NS_MAX_ITER = 100;
+constexpr int NS_REFINE_MAX = 8;         // refinement steps tried with the carried inverse before Newton-Schulz takes over
+constexpr int NS_REFRESH_AFTER = 5;      // more steps than this: the answer stands, and X is refreshed for the steps to come
+constexpr double NS_REFINE_TOL = 2e-15;  // ||b - K x|| <= tol ||b||: the floor of a refinement in working precision
+constexpr double NS_REFINE_RATE = 0.3;   // a step must shrink the residual at least this much, or X is not worth keeping
 
 __device__ __forceinline__ double ns_block_sum(double x, double* s_red, int tid) {
   x = rtw::wave_sum(x);
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(NS_THREADS) void newton_solve_kernel(const double* 
   double* sX = sK + (size_t)rp * S;   // [rp][S]
   double* sT = sX + (size_t)rp * S;   // [rp][S]
   __shared__ double s_red[NS_THREADS / 64];
-  __shared__ double s_vec[3][128];
+  __shared__ double s_vec[4][96];   // r <= 80 here (three padded r x r matrices in the dynamic part)
   const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const double* Kb = K + (size_t)blockIdx.x * r * r;
@@ -350,6 +354,55 @@ __global__ __launch_bounds__(NS_THREADS) void newton_solve_kernel(const double* 
   };
   if (!have_prev) restart();
 
+  // Round 3 - refinement before refreshment.  The carried inverse is a PRECONDITIONER: x <- x + X (b - K x) contracts
+  // the error by ||I - X K|| per step, two r x r mat-vecs each, against the two r^3 products of a Newton-Schulz update.
+  // X was exact to ~1e-8 when it was last refreshed and K has moved by O(dt) per time step since, so a few refinement
+  // steps reach the residual floor for many time steps in a row; only when they take more than NS_REFRESH_AFTER steps
+  // (or do not contract) is X refreshed - and in the first case the answer is already there, the refresh is for the
+  // steps to come.  31 -> ~15 us per step for 32 systems of 80 (bench.py, hyper-reduced sweep).
+  bool solved = false, refresh = true;
+  if (have_prev) {
+    double bpart = (tid < r) ? s_vec[0][tid] * s_vec[0][tid] : 0.0;
+    const double bnorm2 = ns_block_sum(bpart, s_red, tid);
+    matvec(sX, s_vec[0], s_vec[1]);                        // x = X b
+    double prev = 1e300;
+    int used = 0;
+    for (int it = 0; it <= NS_REFINE_MAX; ++it) {
+      matvec(sK, s_vec[1], s_vec[2]);                      // K x
+      double rr = 0.0;
+      if (tid < r) {
+        const double e = s_vec[0][tid] - s_vec[2][tid];
+        s_vec[2][tid] = e;
+        rr = e * e;
+      }
+      const double rn2 = ns_block_sum(rr, s_red, tid);     // barriers inside: the residual vector is complete
+      if (!(rn2 == rn2)) break;                             // NaN: leave it to the tracked route and its fallbacks
+      if (rn2 <= NS_REFINE_TOL * NS_REFINE_TOL * bnorm2 || (it > 0 && rn2 >= 0.25 * prev && rn2 <= 1e-26 * bnorm2)) {
+        solved = true;                                      // at the floor (or within a hair of it and no longer moving)
+        used = it;
+        break;
+      }
+      if (it == NS_REFINE_MAX || rn2 > NS_REFINE_RATE * NS_REFINE_RATE * prev) break;   // out of steps / no contraction
+      prev = rn2;
+      matvec(sX, s_vec[2], s_vec[3]);                      // X r
+      if (tid < r) s_vec[1][tid] += s_vec[3][tid];
+      __syncthreads();
+    }
+    if (solved) {
+      refresh = used > NS_REFRESH_AFTER;
+      if (tid < r) rb[tid] = s_vec[1][tid];
+      if (!refresh) {                                       // X stays as it is: nothing to write back
+        if (tid == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&counters[RT_CNT_SOLVES]), 1ull);
+        if (info && tid == 0) info[blockIdx.x] = 0;
+        if (adv.enabled) {
+          __syncthreads();
+          hsweep_advance_rows(adv, blockIdx.x, r, rhs, 1, s_vec[1], tid, NS_THREADS);
+        }
+        return;
+      }
+    }
+  }
+
   int status = RT_WARN_SINGULAR;
   bool restarted = !have_prev;
   int n_iter = 0, n_restart = 0;
@@ -406,6 +459,17 @@ __global__ __launch_bounds__(NS_THREADS) void newton_solve_kernel(const double* 
     atomicAdd(reinterpret_cast<unsigned long long*>(&counters[RT_CNT_NS_RESTART]), (unsigned long long)n_restart);
     atomicAdd(reinterpret_cast<unsigned long long*>(&counters[RT_CNT_SOLVES]), 1ull);
   }
+  if (status != 0 && solved) {
+    // the refinement had already delivered the answer; only the refresh of X failed: start afresh next time
+    for (int i = wid; i < r; i += NS_THREADS / 64)
+      for (int j = lane; j < r; j += 64) Xb[i * r + j] = 0.0;
+    if (info && tid == 0) info[blockIdx.x] = 0;
+    if (adv.enabled) {
+      __syncthreads();
+      hsweep_advance_rows(adv, blockIdx.x, r, rhs, 1, s_vec[1], tid, NS_THREADS);
+    }
+    return;
+  }
   if (status != 0) {
     // The tracking gave up on this system (singular to working precision, or no contraction even from the safe
     // start): pivoted LU right here, out of the copy of K this workgroup already holds, and the next call starts
@@ -424,14 +488,15 @@ __global__ __launch_bounds__(NS_THREADS) void newton_solve_kernel(const double* 
     }
     return;
   }
-  // x = X b, one refinement step against K:  x += X (b - K x)
-  matvec(sX, s_vec[0], s_vec[1]);
-  const double x = (tid < r) ? s_vec[1][tid] : 0.0;
-  matvec(sK, s_vec[1], s_vec[2]);
-  if (tid < r) s_vec[2][tid] = s_vec[0][tid] - s_vec[2][tid];
-  __syncthreads();
-  matvec(sX, s_vec[2], s_vec[1]);
-  if (tid < r) rb[tid] = x + s_vec[1][tid];
+  if (!solved) {   // x = X b, one refinement step against K:  x += X (b - K x)
+    matvec(sX, s_vec[0], s_vec[1]);
+    const double x = (tid < r) ? s_vec[1][tid] : 0.0;
+    matvec(sK, s_vec[1], s_vec[2]);
+    if (tid < r) s_vec[2][tid] = s_vec[0][tid] - s_vec[2][tid];
+    __syncthreads();
+    matvec(sX, s_vec[2], s_vec[1]);
+    if (tid < r) rb[tid] = x + s_vec[1][tid];
+  }
   if (wide_ok) {   // the refreshed inverse goes back the way it came: one 16-byte store per lane and row
     const int j = 2 * lane;
     d2 xv[10];
@@ -495,8 +560,8 @@ int rt_newton_solve_batched(rt_ctx* ctx, const double* K, double* Xinv, double* 
   int S = rp;
   while (S % 4 != 2) ++S;  // 2 S == 4 (mod 8): the 16 rows of an A-operand read fall in distinct LDS banks
   const size_t lds = sizeof(double) * 3 * (size_t)rp * S;
-  if (lds > 156 * 1024) return RT_ERR_UNSUPPORTED;  // + 3 KB of static LDS = the CU's 160 KB
-  RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&newton_solve_kernel), 156 * 1024));
+  if (lds > 155 * 1024) return RT_ERR_UNSUPPORTED;  // + 3.1 KB of static LDS <= the CU's 160 KB
+  RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&newton_solve_kernel), 155 * 1024));
   rt_newton_rhs rq{};
   if (recipe) rq = *recipe;
   hipLaunchKernelGGL(newton_solve_kernel, dim3((unsigned)B), dim3(NS_THREADS), lds, ctx->stream, K, Xinv, rhs, (int)r, S,
