@@ -476,3 +476,103 @@ class PodLanes:
 
     def map(self, snapshot_sets, num=None, normalize=True, tol=None, cap=64):
         return list(self.run(snapshot_sets, num=num, normalize=normalize, tol=tol, cap=cap))
+
+
+class PodWorkers:
+    """Many independent PODs of ANY kind, up to eight at a time: every snapshot set runs ``pod.pod_device`` - the regular
+    route with everything it knows: ``tol`` / ``num`` / default truncation, deflated levels for deep spectra, the
+    Rayleigh-Ritz step for clusters - in a worker thread, on a stream of its own, through a Context of its own whose
+    eigensolver team works on an XCD of its own (option "eig_xcd").
+
+    ``PodLanes`` enqueues whole chains ahead of the spectrum from ONE thread, which is the cheapest form when the number
+    of modes is known beforehand and the spectrum is shallow; a set that turns out deep (sigma_r / sigma_1 < 1e-2 - every
+    energy tolerance below ~1e-4, i.e. the tree walks' usual setting, rom.py:335) is recomputed there one after the
+    other.  Here the host-side decisions of a deep POD (how many modes a level accepts) are taken by the set's own
+    thread while the other threads' kernels run: the device sees up to eight dependent chains at once whatever their
+    kind.  Sets of up to 1024 columns go through ``rt_pod_orth`` - one foreign call per POD, interpreter lock released;
+    wider ones through ``pod.pod_device``, whose host work holds the lock between its waits.  Results come back in
+    order."""
+
+    def __init__(self, workers: int = 8, device=None):
+        import concurrent.futures
+        import queue
+
+        if not torch.cuda.is_available():
+            raise _lib.RomtimeHipError("no MI355X visible: romtime_amd's hot path runs on the GPU only")
+        if not (1 <= int(workers) <= 8):
+            raise ValueError("workers must be 1 .. 8 (one eigensolver team per XCD)")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+        self.workers = int(workers)
+        ids = queue.Queue()
+        for i in range(self.workers):
+            ids.put(i)
+        self._tls = __import__("threading").local()
+        dev = self.device
+
+        def init():
+            torch.cuda.set_device(dev)
+            self._tls.index = ids.get()
+            self._tls.stream = torch.cuda.Stream(dev)
+            with torch.cuda.stream(self._tls.stream):
+                ctx = _lib.Context.current()           # this thread's own rt_ctx (own arenas, own counters)
+                ctx.set_option("eig_xcd", self._tls.index)
+
+        self.pool = concurrent.futures.ThreadPoolExecutor(max_workers=self.workers, initializer=init,
+                                                          thread_name_prefix="romtime-pod")
+
+    def _job(self, X, ready, kwargs):
+        st = self._tls.stream
+        with torch.cuda.stream(st):
+            st.wait_event(ready)                       # the set was produced on the caller's stream
+            n = X.shape[1]
+            if 3 <= n <= 1024:
+                # the composite C entry point: the whole POD (truncation rule, deflated levels, Rayleigh-Ritz) in ONE
+                # foreign call, during which the interpreter lock is released - the worker threads then really run side
+                # by side (with pod.pod_device the Python between a deep POD's kernels serialised them: 1.3x for eight)
+                Q, s, energy, levels = ops.pod_orth(X, num=kwargs["num"], tol=kwargs["tol"], normalize=kwargs["normalize"])
+                out = dict(Q=Q, s=s, energy=energy, VT=None, r=int(Q.shape[1]), passes=1 if levels <= 1 else "deflate",
+                           levels=levels, colnorm=None)
+            else:
+                out = pod.pod_device(X, **kwargs)
+            done = torch.cuda.Event()
+            done.record(st)
+        return out, done
+
+    def run(self, snapshot_sets, num=None, tol=None, normalize=True):
+        """Generator over the results of ``pod.pod_device(X, num=num, tol=tol, normalize=normalize)`` for every X of
+        ``snapshot_sets`` (any iterable, also a lazy one), in order; up to ``workers`` sets are in flight."""
+        main = torch.cuda.current_stream(self.device)
+        kwargs = dict(num=num, tol=tol, normalize=bool(normalize))
+        pending = collections.deque()
+        it = iter(snapshot_sets)
+
+        def admit():
+            try:
+                X = next(it)
+            except StopIteration:
+                return False
+            if X.dim() != 2 or not X.is_cuda or X.dtype != torch.float64:
+                raise _lib.RomtimeHipError("PodWorkers takes 2-D float64 CUDA tensors")
+            ready = torch.cuda.Event()
+            ready.record(main)
+            pending.append((X, self.pool.submit(self._job, X, ready, kwargs)))
+            return True
+
+        for _ in range(self.workers):
+            if not admit():
+                break
+        while pending:
+            X, fut = pending.popleft()
+            out, done = fut.result()                   # re-raises what the POD raised (ValueError on a zero-norm set, ...)
+            main.wait_event(done)
+            for t in (out["Q"], out.get("colnorm")):
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(main)              # allocated under the worker's stream, used by the caller's
+            admit()
+            yield out
+
+    def map(self, snapshot_sets, num=None, tol=None, normalize=True):
+        return list(self.run(snapshot_sets, num=num, tol=tol, normalize=normalize))
+
+    def close(self):
+        self.pool.shutdown(wait=True)

@@ -24,6 +24,7 @@ DESIGN.md "POD accuracy").
 from __future__ import annotations
 
 import ctypes as C
+import threading
 
 import numpy as np
 import torch
@@ -83,6 +84,7 @@ def _profiling(ctx) -> bool:
 
 
 _THREADPOOLS = None  # threadpoolctl.ThreadpoolController, built once: scanning the loaded libraries takes ~2 ms
+_HOST_DENSE_LOCK = threading.RLock()   # the pool limits are process-wide: one host dense step at a time
 
 
 class _blas_threads:
@@ -95,6 +97,7 @@ class _blas_threads:
 
     def __enter__(self):
         global _THREADPOOLS
+        _HOST_DENSE_LOCK.acquire()
         try:
             if _THREADPOOLS is None:
                 from threadpoolctl import ThreadpoolController
@@ -106,8 +109,11 @@ class _blas_threads:
             self.ctx = None
 
     def __exit__(self, *exc):
-        if self.ctx is not None:
-            self.ctx.__exit__(*exc)
+        try:
+            if self.ctx is not None:
+                self.ctx.__exit__(*exc)
+        finally:
+            _HOST_DENSE_LOCK.release()
 
 
 def _eigh_desc(G: np.ndarray):
@@ -247,7 +253,7 @@ class _SmallEig:
         return ops.gemm_nn(Z, ops.to_device(C, Z.device))
 
 
-_PINNED: dict = {}
+_PINNED_TLS = threading.local()   # per thread: concurrent PODs (pipeline.PodWorkers) must not share a staging buffer
 
 
 def _fetch_beside(head: torch.Tensor, enqueue) -> np.ndarray:
@@ -256,9 +262,12 @@ def _fetch_beside(head: torch.Tensor, enqueue) -> np.ndarray:
     dev = head.device
     main = torch.cuda.current_stream(dev)
     key = (dev.index, head.numel())
-    if key not in _PINNED:
-        _PINNED[key] = (torch.empty(head.numel(), dtype=torch.float64).pin_memory(), torch.cuda.Stream(dev))
-    pinned, side = _PINNED[key]
+    cache = getattr(_PINNED_TLS, "buffers", None)
+    if cache is None:
+        cache = _PINNED_TLS.buffers = {}
+    if key not in cache:
+        cache[key] = (torch.empty(head.numel(), dtype=torch.float64).pin_memory(), torch.cuda.Stream(dev))
+    pinned, side = cache[key]
     ready = torch.cuda.Event()
     ready.record(main)
     head.record_stream(side)

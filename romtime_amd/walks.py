@@ -5,10 +5,11 @@ N-MDEIM basis level) followed by the POD of their concatenated bases.  The refer
 the host and ``np.hstack``s the bases.  Here
 
   * every snapshot set is uploaded once, when its turn comes (the FOM callbacks that produce it stay on the host),
-  * the PODs of a level run through ``pipeline.PodLanes`` - eight chains on the chip at a time, one eigensolver team
-    per XCD, everything enqueued ahead of the spectrum; orth's truncation rule (``tol`` > ``num`` > 1e-7) is applied to
-    the spectrum afterwards, and a set whose spectrum needs deflated levels or a Rayleigh-Ritz step is recomputed on
-    the regular route (``pod.pod_device``), so the results are those of ``orth`` set by set,
+  * the PODs of a level run eight at a time through ``pipeline.PodWorkers``: one thread, stream and context per set,
+    its eigensolver team on an XCD of its own, the whole POD - truncation rule, deflated levels for the deep spectra
+    that the walks' energy tolerances ask for, Rayleigh-Ritz for clusters - in one foreign call (``rt_pod_orth``) with
+    the interpreter lock released, so the results are those of ``orth`` set by set (``pipeline.PodLanes``, which
+    enqueues whole chains ahead of the spectrum from one thread, remains for ``num`` truncation of shallow spectra),
   * the bases never leave the device: the next level's snapshot matrix is ``torch.cat`` of them, and only the final
     basis (the classes keep NumPy attributes, as the reference's pickles do) and the spectra of the reports come back.
 """
@@ -23,16 +24,24 @@ from . import ops, pod
 _tls = threading.local()
 
 
-def _lanes(device):
-    from .pipeline import PodLanes
+def _runner(device, kind):
+    from .pipeline import PodLanes, PodWorkers
 
-    cache = getattr(_tls, "lanes", None)
+    cache = getattr(_tls, "runners", None)
     if cache is None:
-        cache = _tls.lanes = {}
-    key = device.index
+        cache = _tls.runners = {}
+    key = (device.index, kind)
     if key not in cache:
-        cache[key] = PodLanes(device=key)
+        cache[key] = PodLanes(device=device.index) if kind == "lanes" else PodWorkers(device=device.index)
     return cache[key]
+
+
+# "workers": every set runs the whole POD in a thread of its own (any truncation rule, deep spectra included);
+# "lanes": whole chains enqueued ahead of the spectrum from one thread (`num` truncation of shallow spectra only: deep
+# sets are recomputed one after the other).  Measured, 16 device-resident sets of 1e5 x 256, 40 modes + the POD of their
+# concatenation: one by one 27.5 ms, lanes 21.1, workers 18.1; 8 deep sets (tol = 1 - 1e-8): 33.4 / 39.8 / 20.9 ms
+# (tools/bench_configs.py walk16, walkdeep).  "auto" = workers.
+MODE = "auto"
 
 
 def pod_sequence(snapshot_sets, num=None, tol=None, normalize=True, cap=64):
@@ -56,7 +65,11 @@ def pod_sequence(snapshot_sets, num=None, tol=None, normalize=True, cap=64):
         for X in chain():
             yield pod.pod_device(X, num=num, tol=tol, normalize=normalize)
         return
-    yield from _lanes(first.device).run(chain(), num=num, tol=tol, normalize=normalize, cap=cap)
+    kind = MODE if MODE != "auto" else "workers"
+    if kind == "lanes":
+        yield from _runner(first.device, "lanes").run(chain(), num=num, tol=tol, normalize=normalize, cap=cap)
+    else:
+        yield from _runner(first.device, "workers").run(chain(), num=num, tol=tol, normalize=normalize)
 
 
 def pod_of_stack(bases, num=None, tol=None, normalize=True):

@@ -244,3 +244,36 @@ def test_process_exits_cleanly_with_pipeline_results_alive():
     res = subprocess.run([sys.executable, "-c", _EXIT_CHILD.format(root=root)], capture_output=True, text=True, timeout=300)
     assert "child done" in res.stdout, res.stderr[-3000:]
     assert res.returncode == 0, (res.returncode, res.stderr[-3000:])
+
+
+def test_workers_match_single_pods_any_truncation():
+    """PodWorkers: every snapshot set's whole POD in a thread, stream and context of its own (rt_pod_orth, interpreter
+    lock released), eight at a time - `tol`, `num` and default truncation, shallow and deep spectra, a set wider than the
+    composite takes (pod.pod_device in the worker), errors re-raised in order."""
+    from romtime_amd import ops, pod
+    from romtime_amd.pipeline import PodWorkers
+
+    rng = np.random.RandomState(21)
+    mats = [_matrix(rng, 6000, 64, 1.0), _matrix(rng, 6000, 64, 9.0), _matrix(rng, 9000, 130, 5.0), _matrix(rng, 4000, 48, 14.0),
+            np.asfortranarray(_matrix(rng, 7001, 96, 3.0)), _matrix(rng, 2500, 1100, 2.0), _matrix(rng, 6000, 64, 1.0) * 3.0,
+            _matrix(rng, 5000, 200, 11.0), _matrix(rng, 6000, 64, 6.0), _matrix(rng, 6000, 80, 2.0)]
+    dev = [ops.to_device(m) for m in mats]
+    workers = PodWorkers()
+    for kw in (dict(tol=1.0 - 1e-9), dict(num=7), dict()):
+        outs = workers.map(dev, normalize=True, **kw)
+        assert len(outs) == len(mats)
+        for X, Xd, out in zip(mats, dev, outs):
+            single = pod.pod_device(Xd, normalize=True, **kw)
+            Qo, so, eo = oracle.orth(X, normalize=True, **kw)
+            assert out["r"] == single["r"] == Qo.shape[1], kw
+            bar = 2e-13 * so[0] + 8 * EPS * so[0] ** 2 / np.maximum(so, 1e-300)
+            assert np.all(np.abs(out["s"] - so) <= bar)
+            Q = out["Q"].cpu().numpy()
+            assert np.abs(Q.T @ Q - np.eye(out["r"])).max() < 1e-9
+            assert np.linalg.norm(Q - Qo @ (Qo.T @ Q), 2) <= 1e-7          # same subspace as dgesvd's columns
+    Z = ops.to_device(np.c_[mats[0][:, :5], np.zeros((6000, 1))])
+    with pytest.raises(ValueError):                                   # zero-norm column + normalize, as orth does
+        workers.map([dev[0], Z, dev[1]], num=3, normalize=True)
+    again = workers.map(dev[:3], num=5, normalize=False)              # the pool works on after an error
+    assert [o["r"] for o in again] == [5, 5, 5]
+    workers.close()

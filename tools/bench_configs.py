@@ -332,17 +332,65 @@ def walk16(n_mu=16, N=100_000, n_t=256, num_t=40, num_mu=40):
 
     ms_lanes, _ = wall_time(lanes, reps=3)
     ms_seq, _ = wall_time(one_by_one, reps=3)
+    walks.MODE = "workers"
+    ms_workers, _ = wall_time(lanes, reps=3)
+    walks.MODE = "auto"
     return dict(config=f"tree walk, {n_mu} mu x ({N} x {n_t}), {num_t} modes per mu, {num_mu} final (DEIM class surface)",
                 device_walk_s=t_dev, host_loop_s=t_host, speedup=t_host / t_dev,
                 sigma_mu_rel_diff=float(np.abs(s_dev - s_host).max() / s_host[0]), subspace_dist=float(sub),
                 basis_after_walk=rep_dev["basis-shape-after-tree-walk"] if "basis-shape-after-tree-walk" in rep_dev else None,
-                device_resident_sets=dict(lanes_ms=ms_lanes, one_by_one_ms=ms_seq, speedup=ms_seq / ms_lanes),
+                device_resident_sets=dict(lanes_ms=ms_lanes, workers_ms=ms_workers, one_by_one_ms=ms_seq, speedup=ms_seq / ms_lanes),
                 note="host-resident snapshots: the walk is bound by the upload of each 205 MB set (pageable memory) and "
                      "the host-side np.array(...).T of the FOM's vectors; the device walk removes the download of every "
                      "time-level basis and the 512 MB re-upload of their concatenation")
 
 
+def walkdeep(n_mu=8, N=100_000, n_t=256, tol_t=1.0 - 1e-8, num_mu=40):
+    """The tree walk with the truncation the reference's drivers use: an energy tolerance at the time level (rom.py:335;
+    tol = 1 - 1e-8 keeps modes down to ~1e-4 sigma_1, so every time-level POD needs deflated levels).  Device-resident
+    sets; the three ways a sequence of such PODs can run: one after the other, through the enqueue-ahead lanes (every
+    set turns out deep and is recomputed one after the other), through the worker threads (the regular route of every set
+    in a thread, stream and context of its own)."""
+    from romtime_amd import walks
+
+    rng = np.random.RandomState(17)
+    sig = 10.0 ** (-16.0 * np.arange(n_t) / (n_t - 1))
+    V0, _ = np.linalg.qr(rng.standard_normal((n_t, n_t)))
+    mix = torch.from_numpy(sig[:, None] * V0.T).cuda()
+    sets = []
+    for j in range(n_mu):
+        U, _ = torch.linalg.qr(torch.randn((N, n_t), dtype=torch.float64, device="cuda"))
+        sets.append((U @ mix) * (1.0 + 0.05 * j))
+        del U
+
+    def run(mode):
+        def go():
+            if mode == "sequential":
+                per = [pod.pod_device(X, tol=tol_t, normalize=True) for X in sets]
+            else:
+                walks.MODE = mode
+                per = list(walks.pod_sequence(sets, tol=tol_t, normalize=True))
+                walks.MODE = "auto"
+            top = walks.pod_of_stack([o["Q"] for o in per], num=num_mu, normalize=False)
+            return per, top
+        return wall_time(go, reps=3)
+
+    out = {}
+    ref = None
+    for mode in ("sequential", "lanes", "workers"):
+        ms, (per, top) = run(mode)
+        out[mode + "_ms"] = ms
+        if ref is None:
+            ref = (per, top)
+        else:
+            assert [o["r"] for o in per] == [o["r"] for o in ref[0]], mode
+            out[mode + "_sigma_rel_diff"] = float(max(np.abs(a["s"] - b["s"]).max() / b["s"][0] for a, b in zip(per, ref[0])))
+    return dict(config=f"tree walk, deep time-level spectra: {n_mu} mu x ({N} x {n_t}), tol_t = 1 - 1e-8 "
+                       f"({[o['r'] for o in ref[0]][:3]}... modes, {ref[0][0]['passes']} route), {num_mu} final; device-resident sets",
+                **out, speedup_workers=out["sequential_ms"] / out["workers_ms"])
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["c2", "c2pipe", "walk16", "c4", "c5", "c5sweep", "c5h"]
+    which = sys.argv[1:] or ["c2", "c2pipe", "walk16", "walkdeep", "c4", "c5", "c5sweep", "c5h"]
     for w in which:
-        print(json.dumps({"c2": c2, "c2pipe": c2pipe, "walk16": walk16, "c4": c4, "c5": c5, "c5sweep": c5sweep, "c5h": c5h}[w]()), flush=True)
+        print(json.dumps({"c2": c2, "c2pipe": c2pipe, "walk16": walk16, "walkdeep": walkdeep, "c4": c4, "c5": c5, "c5sweep": c5sweep, "c5h": c5h}[w]()), flush=True)
