@@ -362,7 +362,12 @@ def main():
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
     group = None
-    if world > 1:
+    force_dist = world == 1 and bool(os.environ.get("ROMTIME_FORCE_COLLECTIVES"))
+    if force_dist:
+        # one rank, but through the process group and its RCCL calls: the rehearsal a one-GPU box allows
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+    distributed = world > 1 or force_dist
+    if distributed:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -384,7 +389,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if distributed:
             import torch.distributed as dist
 
             dist.barrier()
@@ -410,7 +415,7 @@ def main():
                 raise
             why_not = repr(exc)
         ok = torch.tensor([0.0 if pipe is None else 1.0], dtype=torch.float64, device=device)
-        if world > 1:
+        if distributed:
             import torch.distributed as dist
 
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # every rank takes the same route
@@ -472,7 +477,7 @@ def main():
     # what would hide a slow step: eigensolver hand-off time-outs, contexts that fell back to the general hand-off form,
     # sets recomputed on the regular route - summed over the ranks (warm-up included) and printed in every line
     fb = torch.tensor(counts, dtype=torch.float64, device=device)
-    if world > 1:
+    if distributed:
         import torch.distributed as dist
 
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -522,7 +527,7 @@ def main():
             line["secondary"] = secondary_online_sweep(ctx, device, nt=args.sweep_steps, n_mu=32, r=80, n_h=100_000,
                                                        with_cpu=not args.no_cpu_baseline)
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if distributed:
         import torch.distributed as dist
 
         dist.destroy_process_group()

@@ -28,6 +28,7 @@ from __future__ import annotations
 
 import collections
 import ctypes as C
+import os
 import weakref
 
 import numpy as np
@@ -127,7 +128,9 @@ class PodPipeline:
         if group is not None:
             import torch.distributed as dist
 
-            if dist.get_world_size(group) > 1:
+            # ROMTIME_FORCE_COLLECTIVES: a one-rank group takes the collective route too - the rehearsal of the RCCL
+            # calls (all-reduce on the CU-masked stream G, broadcast on stream C) that a one-GPU box allows
+            if dist.get_world_size(group) > 1 or os.environ.get("ROMTIME_FORCE_COLLECTIVES"):
                 self.group_e = dist.new_group(ranks=dist.get_process_group_ranks(group), backend=dist.get_backend(group))
                 self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.sC = torch.cuda.Stream(self.device) if self.group_e is not None else None   # broadcasts of eigen-results
