@@ -192,6 +192,13 @@ int rt_project_csr_batched(rt_ctx* ctx, const int64_t* indptr, const int64_t* in
  * K (B x r x r row-major) is left untouched (the factors are not an output), rhs (B x r) is overwritten with x.
  * info (B device ints, may be NULL): 0, or RT_WARN_SINGULAR. r <= 128. */
 int rt_dense_solve_batched(rt_ctx* ctx, double* K, double* rhs, int64_t r, int64_t B, int* info);
+/* K X = B for many right-hand sides against ONE r x r matrix (r <= 128): K row-major (device, untouched), B and X
+ * r x nrhs row-major (device, distinct), *info (device int, may be NULL) = RT_WARN_SINGULAR on an exactly zero pivot.
+ * Pivoted LU in LDS, one thread per right-hand side.  Replaces np.linalg.solve(PT_U.T, basis_rom.T) - the theta solve of
+ * deim.py:477-493 applied once to every column of a projected collateral basis, when the interpolation matrix is folded
+ * into the expansion of a hyper-reduced operator (romtime_amd/sweep.py). */
+int rt_dense_solve_multi(rt_ctx* ctx, const double* K, int64_t r, const double* B, double* X, int64_t nrhs, int* info);
+
 
 /* The same solve for a SEQUENCE of slowly changing matrices (the reduced systems of consecutive time steps differ by
  * O(dt)): K_b^-1 is tracked in Xinv (B x r x r, caller-owned device memory carried from call to call) and refreshed by

@@ -54,6 +54,7 @@ SIGNATURES = {
     "rt_project_csr": (_int, [_p, _p, _p, _p, _i64, _p, _i64, _i64, _p]),
     "rt_project_csr_batched": (_int, [_p, _p, _p, _p, _i64, _int, _i64, _i64, _p, _i64, _i64, _p]),
     "rt_dense_solve_batched": (_int, [_p, _p, _p, _i64, _i64, _p]),
+    "rt_dense_solve_multi": (_int, [_p, _p, _i64, _p, _p, _i64, _p]),
     "rt_tracked_solve_batched": (_int, [_p, _p, _p, _p, _i64, _i64, _int, _p]),
     "rt_rom_bdf_sweep": (_int, [_p, _p, _p]),
     "rt_hrom_bdf_sweep": (_int, [_p, _p, _p]),

@@ -31,8 +31,12 @@ constexpr int SOLVE_BATCH = 4;
 // right-hand side b (LDS, overwritten); the solution goes to xout (global, r values).  NT threads, all of which must
 // call it; `parts` threads share a row.  Returns 1 when a pivot was exactly zero.  The matrix and b must be in LDS
 // and visible (barrier) on entry; xout is complete after the caller's next barrier.
+// `perm_out` (LDS, r ints, optional): the pivot row of every column; with it the multipliers are kept in place of the
+// eliminated entries (A[i][c] = l_ic for the rows i still live at column c), so that further right-hand sides can be
+// solved against the factors (dense_solve_multi_kernel).
 template <int NT>
-__device__ __forceinline__ int lu_solve_lds(double* A, int lda, double* b, int r, int parts, double* rb) {
+__device__ __forceinline__ int lu_solve_lds(double* A, int lda, double* b, int r, int parts, double* rb,
+                                            int* perm_out = nullptr) {
   constexpr int WAVES = NT / 64;
   __shared__ double s_pv[2][WAVES];
   __shared__ int s_pi[2][WAVES];
@@ -44,6 +48,8 @@ __device__ __forceinline__ int lu_solve_lds(double* A, int lda, double* b, int r
   double* Ar = A + (owner ? row : 0) * lda;
   int sing = 0;
   int cm = 1 % parts;  // (c + 1) mod parts
+  double l_keep = 0.0;
+  int c_keep = -1;
 
   double cand = (owner && part == 0) ? fabs(Ar[0]) : -1.0;  // candidates of column 0
   for (int c = 0; c < r; ++c) {
@@ -54,6 +60,10 @@ __device__ __forceinline__ int lu_solve_lds(double* A, int lda, double* b, int r
       s_pi[c & 1][wid] = ci;
     }
     __syncthreads();
+    if (c_keep >= 0) {
+      Ar[c_keep] = l_keep;
+      c_keep = -1;
+    }
     double best = s_pv[c & 1][0];
     int pr = s_pi[c & 1][0];
 #pragma unroll
@@ -72,6 +82,10 @@ __device__ __forceinline__ int lu_solve_lds(double* A, int lda, double* b, int r
     if (!retired) {
       const double* Ap = A + pr * lda;
       const double l = Ar[c] / Ap[c];
+      if (perm_out && part == 0) {   // written after the NEXT barrier: the row's other threads are reading Ar[c] now
+        l_keep = l;
+        c_keep = c;
+      }
       // first owned column after c: c + 1 + ((part - (c + 1)) mod parts)
       int d = part - cm;
       if (d < 0) d += parts;
@@ -97,6 +111,11 @@ __device__ __forceinline__ int lu_solve_lds(double* A, int lda, double* b, int r
     if (++cm == parts) cm = 0;
   }
   __syncthreads();
+  if (perm_out) {
+    if (c_keep >= 0) Ar[c_keep] = l_keep;
+    for (int c = tid; c < r; c += NT) perm_out[c] = s_perm[c];
+    __syncthreads();
+  }
 
   // back substitution over the pivot order: x_c = b[p_c] / A[p_c][c];  b[p_k] -= A[p_k][c] x_c for k < c
   if (wid == 0) {
@@ -142,6 +161,46 @@ __global__ __launch_bounds__(SOLVE_THREADS) void dense_solve_kernel(const double
   if (adv.enabled) {  // the hyper-reduced sweep's end of step for this system (its solver kernel left it alone)
     __syncthreads();  // rb is complete and visible in this workgroup
     hsweep_advance_rows(adv, blockIdx.x, r, rhs, 1, b, tid, SOLVE_THREADS);
+  }
+}
+
+// K X = B for MANY right-hand sides against one matrix (folding an interpolation matrix PT_U into the expansion of a
+// hyper-reduced operator, Z = basis_rom PT_U^-1: np.linalg.solve with r^2 right-hand sides in the reference's terms,
+// deim.py:477-493 applied once to every column).  Every workgroup factorises K for itself in LDS (pivoted LU with the
+// multipliers kept) and then gives each of its threads one right-hand side: forward and back substitution in pivot
+// order, the column's intermediate values in the output array (coalesced across the threads: the right-hand-side index
+// runs fastest), the factors broadcast out of LDS.
+__global__ __launch_bounds__(SOLVE_THREADS) void dense_solve_multi_kernel(const double* __restrict__ K, int r, int parts,
+                                                                          const double* __restrict__ B,
+                                                                          double* __restrict__ X, long nrhs, int* info) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int lda = r | 1;
+  double* A = sm;                                    // r x lda
+  double* dummy = sm + (size_t)r * lda;              // r: the single right-hand side lu_solve_lds carries along
+  int* perm = reinterpret_cast<int*>(dummy + r);     // r
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  for (int i = wid; i < r; i += SOLVE_WAVES)
+    for (int j = lane; j < r; j += 64) A[i * lda + j] = K[(size_t)i * r + j];
+  for (int e = tid; e < r; e += SOLVE_THREADS) dummy[e] = 0.0;
+  __syncthreads();
+  const int sing = lu_solve_lds<SOLVE_THREADS>(A, lda, dummy, r, parts, dummy, perm);   // (its own solve goes to LDS, unused)
+  __syncthreads();
+  if (info && tid == 0 && blockIdx.x == 0) info[0] = sing ? RT_WARN_SINGULAR : 0;
+  const long col = (long)blockIdx.x * SOLVE_THREADS + tid;
+  if (col >= nrhs) return;
+  // forward: y_c = b[p_c] - sum_{k<c} L[p_c][k] y_k   (row p_c was live at every column k < c: its multipliers sit there)
+  for (int c = 0; c < r; ++c) {
+    const double* row = A + perm[c] * lda;
+    double acc = B[(size_t)perm[c] * nrhs + col];
+    for (int k = 0; k < c; ++k) acc = fma(-row[k], X[(size_t)k * nrhs + col], acc);
+    X[(size_t)c * nrhs + col] = acc;
+  }
+  // back: x_c = (y_c - sum_{k>c} U[p_c][k] x_k) / U[p_c][c]
+  for (int c = r - 1; c >= 0; --c) {
+    const double* row = A + perm[c] * lda;
+    double acc = X[(size_t)c * nrhs + col];
+    for (int k = c + 1; k < r; ++k) acc = fma(-row[k], X[(size_t)k * nrhs + col], acc);
+    X[(size_t)c * nrhs + col] = acc / row[c];
   }
 }
 
@@ -546,6 +605,26 @@ static int dense_solve_launch(rt_ctx* ctx, double* K, double* rhs, int64_t r, in
   if (parts > 8) parts = 8;
   hipLaunchKernelGGL(dense_solve_kernel, dim3((unsigned)B), dim3(SOLVE_THREADS), lds, ctx->stream, K, rhs, (int)r,
                      parts, info, only_if, ctx->dev_counters, advance ? *advance : rt_advance{});
+  RT_HIP_CHECK(ctx, hipGetLastError());
+  return RT_OK;
+}
+
+extern "C" int rt_dense_solve_multi(rt_ctx* ctx, const double* K, int64_t r, const double* B, double* X, int64_t nrhs,
+                                   int* info) {
+  if (!ctx) return RT_ERR_ARG;
+  RT_ARG_CHECK(ctx, K && B && X && B != X && r >= 1 && nrhs >= 1);
+  if (r > 128) {
+    ctx->err = "rt_dense_solve_multi: r > 128 not supported (the factors must fit the CU's LDS)";
+    return RT_ERR_UNSUPPORTED;
+  }
+  const int lda = (int)r | 1;
+  const size_t lds = sizeof(double) * ((size_t)r * lda + r) + sizeof(int) * (size_t)r;
+  RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&dense_solve_multi_kernel), 140 * 1024));
+  int parts = SOLVE_THREADS / (int)r;
+  if (parts > 8) parts = 8;
+  const unsigned grid = (unsigned)((nrhs + SOLVE_THREADS - 1) / SOLVE_THREADS);
+  hipLaunchKernelGGL(dense_solve_multi_kernel, dim3(grid), dim3(SOLVE_THREADS), lds, ctx->stream, K, (int)r, parts, B, X,
+                     (long)nrhs, info);
   RT_HIP_CHECK(ctx, hipGetLastError());
   return RT_OK;
 }

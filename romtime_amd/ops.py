@@ -242,6 +242,20 @@ def dense_solve(K: torch.Tensor, b: torch.Tensor):
     return (bw[0] if single else bw), info
 
 
+def dense_solve_multi(K: torch.Tensor, B: torch.Tensor):
+    """X with K X = B for an r x r matrix (r <= 128) and r x nrhs right-hand sides.  Returns (X, info).
+    rt_dense_solve_multi."""
+    ctx = Context.current()
+    K, B = K.contiguous(), B.contiguous()
+    r, nrhs = B.shape
+    if tuple(K.shape) != (r, r):
+        raise RomtimeHipError("dense_solve_multi: K must be r x r and B r x nrhs")
+    X = torch.empty_like(B)
+    info = torch.zeros(1, dtype=torch.int32, device=K.device)
+    ctx.check(ctx.lib.rt_dense_solve_multi(ctx.handle, _ptr(K), r, _ptr(B), _ptr(X), nrhs, _ptr(info)), "rt_dense_solve_multi")
+    return X, info
+
+
 def pod_enqueue(X: torch.Tensor, k: int, normalize: bool):
     """One single-pass POD enqueued on the ctx stream with ONE host call (rt_pod_enqueue): returns the device tensors
     (Q, lam, status2, colnorm) and a tuple of the work buffers to keep alive until the stream has run them."""

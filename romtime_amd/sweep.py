@@ -59,8 +59,14 @@ def hrom_bdf_sweep(mass, lin, nl, rhs, dt, bdf2=True):
 
     ctx = Context.current()
 
-    def fold(term):  # rows = the r x r (or r) arrays multiplied by each local entry
-        return np.linalg.solve(np.asarray(term["PT_U"], dtype=np.float64).T, np.asarray(term["basis_rom"], dtype=np.float64).T)
+    def fold(term):  # rows = the r x r (or r) arrays multiplied by each local entry: PT_U^T Z = basis_rom^T
+        PT_U, basis_rom = np.asarray(term["PT_U"], dtype=np.float64), np.asarray(term["basis_rom"], dtype=np.float64)
+        if PT_U.shape[0] > 128:   # beyond the LDS-resident factorisation (include/romtime_hip.h): host LAPACK
+            return np.linalg.solve(PT_U.T, basis_rom.T)
+        Zt, info = ops.dense_solve_multi(ops.to_device(np.ascontiguousarray(PT_U.T)), ops.to_device(np.ascontiguousarray(basis_rom.T)))
+        if int(info.item()) != 0:
+            raise np.linalg.LinAlgError("Singular matrix")           # what np.linalg.solve raises (deim.py:491-492)
+        return Zt.cpu().numpy()
 
     blocks = [fold(mass)] + [fold(t) for t in lin] + ([fold(nl)] if nl is not None else [])
     rr = blocks[0].shape[1]

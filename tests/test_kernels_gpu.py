@@ -7,6 +7,7 @@ from scipy.sparse import csr_matrix
 from oracle import romtime_oracle as oracle
 
 pytestmark = pytest.mark.gpu
+EPS = 2.2e-16
 
 
 @pytest.fixture(scope="module")
@@ -400,6 +401,31 @@ def test_device_sweep_takes_any_number_of_terms_and_points():
     assert np.linalg.norm(big - small) <= 1e-11 * np.linalg.norm(small)
     ref, _ = oracle.rom_solve_nonlinear(fom, V, mus[7], solver=np.linalg.solve)
     assert np.linalg.norm(big[7].T - ref) <= 1e-10 * np.linalg.norm(ref)
+
+
+@pytest.mark.parametrize("m,nrhs", [(120, 6400), (37, 257), (128, 1000), (1, 5), (80, 80)])
+def test_dense_solve_multi_matches_lapack(ops, m, nrhs):
+    """rt_dense_solve_multi: K X = B for many right-hand sides against one matrix (the fold of PT_U into a hyper-reduced
+    operator's expansion, romtime_amd/sweep.py) against np.linalg.solve; a matrix that needs its pivoting; an exactly
+    singular one is reported."""
+    rng = np.random.RandomState(m)
+    K = rng.standard_normal((m, m))
+    if m > 2:
+        K[0, 0] = 0.0                      # the first pivot cannot be the diagonal entry
+        K[[1, 2]] = K[[2, 1]]
+    B = rng.standard_normal((m, nrhs))
+    X, info = ops.dense_solve_multi(ops.to_device(K), ops.to_device(B))
+    ref = np.linalg.solve(K, B)
+    assert int(info.item()) == 0
+    cond = np.linalg.cond(K)
+    assert np.abs(X.cpu().numpy() - ref).max() <= 50 * EPS * cond * np.abs(ref).max()
+    resid = np.abs(K @ X.cpu().numpy() - B).max()
+    assert resid <= 200 * EPS * m * np.abs(K).max() * np.abs(ref).max()
+    if m > 2:
+        Ks = K.copy()
+        Ks[:, 3 % m] = 0.0
+        _, info = ops.dense_solve_multi(ops.to_device(Ks), ops.to_device(B))
+        assert int(info.item()) != 0
 
 
 def test_hyper_reduced_sweep_synthetic_and_singular_system(ops):

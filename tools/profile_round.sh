@@ -20,10 +20,25 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES
 python3 $R/tools/bench_configs.py > $DEST/${ROUND}_configs_${TAG}.jsonl 2> $O/configs.log || exit 6
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/sweep_stats -- python3 $R/tools/bench_configs.py c5sweep > $O/sweep.log 2>&1 || exit 7
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/hsweep_stats -- python3 $R/tools/bench_configs.py c5h > $O/hsweep.log 2>&1 || exit 8
+# counter passes of the other kernels DESIGN.md quotes: the direct sweep (project_fused, sweep_values, newton_solve), the
+# hyper-reduced sweep (expansion GEMM, newton_solve) and config 4 (deim_*, project_fused at 120 vectors, tallskinny, rank_update)
+SQ="SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA"
+n=20
+for W in c5sweep c5h c4; do
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/${W}_fetch -- python3 $R/tools/bench_configs.py $W > $O/${W}_fetch.log 2>&1 || exit $n
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/${W}_write -- python3 $R/tools/bench_configs.py $W > $O/${W}_write.log 2>&1 || exit $((n+1))
+  rocprofv3 --pmc $SQ --output-format csv -d $O/${W}_sq -- python3 $R/tools/bench_configs.py $W > $O/${W}_sq.log 2>&1 || exit $((n+2))
+  n=$((n+3))
+done
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4_stats -- python3 $R/tools/bench_configs.py c4 > $O/c4.log 2>&1 || exit 30
 cd $R
 python3 tools/summarize_prof.py ${ROUND}_bench_${TAG} --stats $O/stats --fetch $O/fetch --write $O/write --sq $O/sq || exit 9
+for W in c5sweep c5h c4; do
+  python3 tools/summarize_prof.py ${ROUND}_${W}_${TAG} --fetch $O/${W}_fetch --write $O/${W}_write --sq $O/${W}_sq --keep project,newton,sweep,gemm,deim,tallskinny,rank_update,gram,symeig,solve || exit 31
+done
+python3 tools/summarize_prof.py ${ROUND}_c4_${TAG} --stats $O/c4_stats --keep none || exit 32
 python3 tools/summarize_prof.py ${ROUND}_sweep_${TAG} --stats $O/sweep_stats || exit 10
 python3 tools/summarize_prof.py ${ROUND}_hsweep_${TAG} --stats $O/hsweep_stats || exit 11
 cp profiles/${ROUND}_*_${TAG}* profiles/gram_traffic.json $DEST/
-rm -f $DEST/*_sweep_*_pmc.json $DEST/*_hsweep_*_pmc.json; rm -rf $O/stats $O/fetch $O/write $O/sq $O/sweep_stats $O/hsweep_stats   # raw output is large; the summaries are what is kept
+rm -f $DEST/*_sweep_${TAG}_pmc.json $DEST/*_hsweep_${TAG}_pmc.json; rm -rf $O/stats $O/fetch $O/write $O/sq $O/sweep_stats $O/hsweep_stats $O/c4_stats $O/*_fetch $O/*_write $O/*_sq   # raw output is large; the summaries are what is kept
 ls -la $DEST

@@ -72,12 +72,19 @@ def main():
     with open(os.path.join(ROOT, "profiles", f"{a.tag}_pmc.json"), "w") as fp:
         json.dump(pmc, fp, indent=1, sort_keys=True)
     gram = [cs["hbm_bytes_per_launch"] for k, cs in pmc.items() if k.startswith("gram128_kernel") and "hbm_bytes_per_launch" in cs]
-    if gram:
+    if gram and "_bench_" in a.tag:   # only the headline workload's passes describe the bench line's Gram
         with open(os.path.join(ROOT, "profiles", "gram_traffic.json"), "w") as fp:
             json.dump(dict(hbm_bytes_per_gram=sum(gram), source=f"profiles/{a.tag}_pmc.json",
                            workload="pod_1000000x512 on 1 GPU (bench.py default)",
                            method="2*FETCH_SIZE*1024 + WRITE_SIZE*1024, separate --pmc passes, summed over the "
                                   "off-diagonal and diagonal launches"), fp, indent=1)
+    proj = [cs for k, cs in pmc.items() if k.startswith("project_fused_kernel<5, false>") and "hbm_bytes_per_launch" in cs]
+    if proj and "_c5sweep_" in a.tag:  # the projection launch of the direct sweep (32 value vectors, r = 80, N = 1e5)
+        with open(os.path.join(ROOT, "profiles", "project_traffic.json"), "w") as fp:
+            json.dump(dict(hbm_bytes_per_launch=proj[0]["hbm_bytes_per_launch"], source=f"profiles/{a.tag}_pmc.json",
+                           workload="project_fused_kernel<5,false>, 32 value vectors on the pentadiagonal pattern, N = 1e5, r = 80 "
+                                    "(tools/bench_configs.py c5sweep)",
+                           method="2*FETCH_SIZE*1024 + WRITE_SIZE*1024, separate --pmc passes"), fp, indent=1)
     for k, cs in pmc.items():
         print(k, {c: (round(v, 4) if v < 1e4 else f"{v:.4g}") for c, v in cs.items()
                   if c in ("hbm_bytes_per_launch", "effective_clock_GHz", "mfma_util", "_dur_ms")})
