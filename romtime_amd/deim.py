@@ -182,7 +182,8 @@ class DiscreteEmpiricalInterpolation(Reductor):
             for mu in space:
                 mu_idx, mu = self.add_mu(step=Stage.OFFLINE, mu=mu)
                 indices.append(mu_idx)
-                yield walks.upload(self._time_level_snapshots(mu, ts))
+                yield walks.upload_columns([self.assemble_snapshot(mu, t) for t in ts],
+                                           zero_first_row=self.TYPE == EmpiricalInterpolation.MDEIM)   # deim.py:384-389
 
         per_mu = []
         for i, out in enumerate(walks.pod_sequence(time_level_sets(), num=num_t, tol=tol_t, normalize=False)):

@@ -108,9 +108,8 @@ class MatrixDiscreteEmpiricalInterpolationNonlinear(MatrixDiscreteEmpiricalInter
 
         def basis_level_sets():
             for t in ts:
-                snapshots = np.array([self.assemble_snapshot(mu=mu, t=t, u_n=u_n[:, i]) for i in range(u_n.shape[1])]).T
-                snapshots[0, :] = 0.0
-                yield walks.upload(snapshots)
+                yield walks.upload_columns([self.assemble_snapshot(mu=mu, t=t, u_n=u_n[:, i]) for i in range(u_n.shape[1])],
+                                           zero_first_row=True)                     # nonlinear.py:437-443
 
         per_t = [out["Q"] for out in walks.pod_sequence(basis_level_sets(), num=num_t, tol=tol_t, normalize=normalize)]
         return walks.pod_of_stack(per_t, num=num_t, tol=tol_t, normalize=normalize)

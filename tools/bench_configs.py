@@ -340,9 +340,10 @@ def walk16(n_mu=16, N=100_000, n_t=256, num_t=40, num_mu=40):
                 sigma_mu_rel_diff=float(np.abs(s_dev - s_host).max() / s_host[0]), subspace_dist=float(sub),
                 basis_after_walk=rep_dev["basis-shape-after-tree-walk"] if "basis-shape-after-tree-walk" in rep_dev else None,
                 device_resident_sets=dict(lanes_ms=ms_lanes, workers_ms=ms_workers, one_by_one_ms=ms_seq, speedup=ms_seq / ms_lanes),
-                note="host-resident snapshots: the walk is bound by the upload of each 205 MB set (pageable memory) and "
-                     "the host-side np.array(...).T of the FOM's vectors; the device walk removes the download of every "
-                     "time-level basis and the 512 MB re-upload of their concatenation")
+                note="host-resident snapshots: per 205 MB set the round-2 loop spends 21 ms in np.array(list).T (page faults of "
+                     "the fresh allocation), 4 ms on the upload, downloads every time-level basis and re-uploads the 512 MB "
+                     "concatenation; the device walk stacks the FOM's vectors straight into reusable pinned memory (9 ms), "
+                     "sends them asynchronously and keeps the bases on the device")
 
 
 def walkdeep(n_mu=8, N=100_000, n_t=256, tol_t=1.0 - 1e-8, num_mu=40):

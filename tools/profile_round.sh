@@ -33,10 +33,11 @@ done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4_stats -- python3 $R/tools/bench_configs.py c4 > $O/c4.log 2>&1 || exit 30
 cd $R
 python3 tools/summarize_prof.py ${ROUND}_bench_${TAG} --stats $O/stats --fetch $O/fetch --write $O/write --sq $O/sq || exit 9
-for W in c5sweep c5h c4; do
-  python3 tools/summarize_prof.py ${ROUND}_${W}_${TAG} --fetch $O/${W}_fetch --write $O/${W}_write --sq $O/${W}_sq --keep project,newton,sweep,gemm,deim,tallskinny,rank_update,gram,symeig,solve || exit 31
+KEEP=project,newton,sweep,gemm,deim,tallskinny,rank_update,gram,symeig,solve
+for W in c5sweep c5h; do
+  python3 tools/summarize_prof.py ${ROUND}_${W}_${TAG} --fetch $O/${W}_fetch --write $O/${W}_write --sq $O/${W}_sq --keep $KEEP || exit 31
 done
-python3 tools/summarize_prof.py ${ROUND}_c4_${TAG} --stats $O/c4_stats --keep none || exit 32
+python3 tools/summarize_prof.py ${ROUND}_c4_${TAG} --stats $O/c4_stats --fetch $O/c4_fetch --write $O/c4_write --sq $O/c4_sq --keep $KEEP || exit 32
 python3 tools/summarize_prof.py ${ROUND}_sweep_${TAG} --stats $O/sweep_stats || exit 10
 python3 tools/summarize_prof.py ${ROUND}_hsweep_${TAG} --stats $O/hsweep_stats || exit 11
 cp profiles/${ROUND}_*_${TAG}* profiles/gram_traffic.json $DEST/
