@@ -132,12 +132,17 @@ class Context:
             raise RomtimeHipError(f"rt_ctx_create(device={device}) failed with {rc}")
         self.handle = h
         self.options = {}
+        self._pid = os.getpid()
 
     def __del__(self):
+        # Not in a forked child: after fork() the interpreter drops the thread states of every thread but the forking
+        # one, and with them the thread-local contexts of worker threads (pipeline.PodWorkers) - their finalisers would
+        # call into a HIP runtime the child must not touch (seen as a segmentation fault in a child of multiprocessing
+        # started after a tree walk had run).  The parent still owns the handle.
         try:
-            if getattr(self, "handle", None):
+            if getattr(self, "handle", None) and getattr(self, "_pid", None) == os.getpid():
                 self.lib.rt_ctx_destroy(self.handle)
-                self.handle = None
+            self.handle = None
         except Exception:
             pass
 

@@ -41,6 +41,7 @@ _p = C.c_void_p
 
 SMALL_SET = 150_000_000   # rows x columns below which a set takes the regular route (see run())
 _STREAMS: dict = {}
+_STREAMS_PID: list = []
 _OPEN_RUNS = weakref.WeakSet()   # PodPipeline.run generators that have not finished (closed by shutdown())
 
 
@@ -55,6 +56,9 @@ def shutdown():
     import gc
 
     if not _STREAMS:
+        return
+    if _STREAMS_PID and _STREAMS_PID[0] != os.getpid():
+        _STREAMS.clear()                      # a forked child: the queues belong to the parent
         return
     try:
         for gen in list(_OPEN_RUNS):
@@ -77,6 +81,7 @@ def _masked_stream(lib, dev, first, count):
         if rc != 0:
             raise _lib.RomtimeHipError(f"rt_stream_create_cu_range({first}, {count}) failed ({rc})")
         _STREAMS[key] = torch.cuda.ExternalStream(h.value, device=torch.device("cuda", dev))
+        _STREAMS_PID[:] = [os.getpid()]
     return _STREAMS[key]
 
 

@@ -277,3 +277,23 @@ def test_workers_match_single_pods_any_truncation():
     again = workers.map(dev[:3], num=5, normalize=False)              # the pool works on after an error
     assert [o["r"] for o in again] == [5, 5, 5]
     workers.close()
+
+
+def test_fork_after_worker_threads_is_safe():
+    """A child forked after PodWorkers has run (multiprocessing.Manager, a DataLoader ...) drops the worker threads'
+    thread-local contexts; their finalisers must not call into HIP there (round 3: segmentation fault in the child)."""
+    import multiprocessing as mp
+
+    from romtime_amd import ops
+    from romtime_amd.pipeline import PodWorkers
+
+    rng = np.random.RandomState(5)
+    workers = PodWorkers(workers=3)
+    outs = workers.map([ops.to_device(_matrix(rng, 3000, 32, 1.0)) for _ in range(4)], num=3)
+    assert len(outs) == 4
+    m = mp.get_context("fork").Manager()       # forks a server process and waits for its address
+    d = m.dict()
+    d["ok"] = 1
+    assert d["ok"] == 1
+    m.shutdown()
+    workers.close()
