@@ -139,6 +139,13 @@ class PodPipeline:
                 self.group_e = dist.new_group(ranks=dist.get_process_group_ranks(group), backend=dist.get_backend(group))
                 self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
         self.sC = torch.cuda.Stream(self.device) if self.group_e is not None else None   # broadcasts of eigen-results
+        # The Gram all-reduce is issued from stream E: only the eigensolve needs the sum, the next Gram on stream G does
+        # not.  Issued from stream G, the collective (ProcessGroupNCCL makes the calling stream wait for its own) put two
+        # cross-stream hand-overs and the all-reduce on the critical stream of every set (one-rank RCCL rehearsal: 6.29 ms
+        # per POD against 5.86 without collectives); a FIFTH stream for it was worse still (7.5 ms: the streams of a
+        # process share a handful of hardware queues, and the Gram's queue picked up false dependencies).  Stream E has
+        # 1.8 ms of slack per set.
+        self.sR = self.sE if self.group_e is not None else None
         self.eig_cus = 8 * e
         self.recomputed = 0                          # sets that failed a check and took the regular route
         self.gram_kernel_ms = []                     # per set: Gram kernels + slab reduction, stream events on stream G
@@ -160,13 +167,22 @@ class PodPipeline:
             Gbuf[n * n:].fill_(float(X.shape[0]))
             item["k0"] = torch.cuda.Event(enable_timing=True)
             item["k0"].record()                                                    # Gram kernels + slab reduction end here
-            if self.group is not None:
-                import torch.distributed as dist
-
-                dist.all_reduce(Gbuf, op=dist.ReduceOp.SUM, group=self.group)
             item["Gbuf"] = Gbuf
-            item["g"] = torch.cuda.Event(enable_timing=True)
-            item["g"].record()
+            if self.sR is None:
+                if self.group is not None:      # a one-rank group without forced collectives: nothing to sum
+                    import torch.distributed as dist
+
+                    dist.all_reduce(Gbuf, op=dist.ReduceOp.SUM, group=self.group)
+                item["g"] = torch.cuda.Event(enable_timing=True)
+                item["g"].record()
+        if self.sR is not None:
+            import torch.distributed as dist
+
+            with torch.cuda.stream(self.sR):
+                self.sR.wait_event(item["k0"])
+                dist.all_reduce(Gbuf, op=dist.ReduceOp.SUM, group=self.group)
+                item["g"] = torch.cuda.Event(enable_timing=True)
+                item["g"].record()
 
     def _eig(self, item):
         """Stream E: the n x n eigenproblem of this set - on every rank of a single-GPU run, on ONE rank (set index mod
