@@ -31,7 +31,7 @@ constexpr int TW_LARGE = 128;  // 512 < n <= 1024: 8 rows of 1024 per workgroup
 constexpr int LPR = 64;     // lanes per matrix row in the mat-vec / rank-2 update (TT / LPR rows per pass)
 constexpr int TT = 1024;    // threads per workgroup
 static_assert(LPR == 64, "row reductions use the whole-wave DPP sum");
-constexpr int NMAX = 1024;     // largest supported n; the kernels are instantiated for 512 and 1024
+constexpr int NMAX = 1024;     // largest supported n; the kernels are instantiated for 128, 256, 512 and 1024
 // inverse iterations per eigenvector: the shifts are eigenvalues to full precision, so the first solve already
 // amplifies the wanted direction by ~1/eps and the second removes what is left of the start vector (dstein also
 // stops after two or three); the caller's Rayleigh-Ritz step cross-checks the result
@@ -683,6 +683,12 @@ extern "C" int rt_sym_eig_values_part(rt_ctx* ctx, const double* G, int64_t n, i
 
   const int RB = (int)((n + tw - 1) / tw);
   const size_t lds = sizeof(double) * ((size_t)RB * n + 4 * n + 16);  // A slab | v (x2) | w | row
+  // n <= 256 has instantiations of its own (round 3): wave 0's register work per column - reflector, w, the updated row:
+  // NM / 64 elements per lane - and the eigenvector kernel's back-transformation halve against the 512 ones
+  static const bool small_nm = !(eig_flags & 2);
+  const bool tiny = small_nm && n <= 256, tinier = small_nm && n <= 128;
+  RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&symeig_tridiag_kernel<128>), 150 * 1024));
+  RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&symeig_tridiag_kernel<256>), 150 * 1024));
   RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&symeig_tridiag_kernel<512>), 150 * 1024));
   RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&symeig_tridiag_kernel<1024>), 150 * 1024));
   {
@@ -692,6 +698,10 @@ extern "C" int rt_sym_eig_values_part(rt_ctx* ctx, const double* G, int64_t n, i
     int per_cu = 0;
     if (large)
       RT_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, symeig_tridiag_kernel<1024>, TT, lds));
+    else if (tinier)
+      RT_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, symeig_tridiag_kernel<128>, TT, lds));
+    else if (tiny)
+      RT_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, symeig_tridiag_kernel<256>, TT, lds));
     else
       RT_HIP_CHECK(ctx, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, symeig_tridiag_kernel<512>, TT, lds));
     if ((long)per_cu * ctx->num_cus < tw) {
@@ -706,7 +716,12 @@ extern "C" int rt_sym_eig_values_part(rt_ctx* ctx, const double* G, int64_t n, i
     hipLaunchKernelGGL(symeig_bisect_kernel<1024>, bgrid, dim3(256), 0, st, tp.d, tp.e, (int)n, (int)first, (int)count,
                        lam, tp.flags, status, ctx->dev_counters);
   } else {
-    hipLaunchKernelGGL(symeig_tridiag_kernel<512>, dim3(tp.spread ? 16 * tw : tw), dim3(TT), lds, st, tp);
+    if (tinier)
+      hipLaunchKernelGGL(symeig_tridiag_kernel<128>, dim3(tp.spread ? 16 * tw : tw), dim3(TT), lds, st, tp);
+    else if (tiny)
+      hipLaunchKernelGGL(symeig_tridiag_kernel<256>, dim3(tp.spread ? 16 * tw : tw), dim3(TT), lds, st, tp);
+    else
+      hipLaunchKernelGGL(symeig_tridiag_kernel<512>, dim3(tp.spread ? 16 * tw : tw), dim3(TT), lds, st, tp);
     RT_HIP_CHECK(ctx, hipGetLastError());
     hipLaunchKernelGGL(symeig_bisect_kernel<512>, bgrid, dim3(256), 0, st, tp.d, tp.e, (int)n, (int)first, (int)count,
                        lam, tp.flags, status, ctx->dev_counters);
@@ -735,6 +750,9 @@ extern "C" int rt_sym_eig_vectors(rt_ctx* ctx, int64_t n, int64_t k, const doubl
   int rc = rt_scratch(ctx, sizeof(double) * 6 * (size_t)nblk, &cbuf);  // leaf arena: free between the two calls
   if (rc != RT_OK) return rc;
   vp.C = static_cast<const double*>(cbuf);
+  static const int eig_flags_v = [] { const char* e = getenv("ROMTIME_EIG_FLAGS"); return e ? atoi(e) : 0; }();
+  RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&symeig_vectors_kernel<128>), 80 * 1024));
+  RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&symeig_vectors_kernel<256>), 80 * 1024));
   RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&symeig_vectors_kernel<512>), 80 * 1024));
   RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&symeig_vectors_kernel<1024>), 80 * 1024));
   if (n > 512) {
@@ -742,6 +760,16 @@ extern "C" int rt_sym_eig_vectors(rt_ctx* ctx, int64_t n, int64_t k, const doubl
     hipLaunchKernelGGL(symeig_wy_kernel<1024>, dim3((unsigned)nblk), dim3(64), 0, ctx->stream, vp.V, (int)n,
                        static_cast<double*>(cbuf));
     hipLaunchKernelGGL(symeig_vectors_kernel<1024>, dim3((unsigned)k), dim3(64), vlds, ctx->stream, vp);
+  } else if (n <= 128 && !(eig_flags_v & 2)) {
+    const size_t vlds = sizeof(double) * (8 * 128 + 8) + 128;
+    hipLaunchKernelGGL(symeig_wy_kernel<128>, dim3((unsigned)nblk), dim3(64), 0, ctx->stream, vp.V, (int)n,
+                       static_cast<double*>(cbuf));
+    hipLaunchKernelGGL(symeig_vectors_kernel<128>, dim3((unsigned)k), dim3(64), vlds, ctx->stream, vp);
+  } else if (n <= 256 && !(eig_flags_v & 2)) {
+    const size_t vlds = sizeof(double) * (8 * 256 + 8) + 256;
+    hipLaunchKernelGGL(symeig_wy_kernel<256>, dim3((unsigned)nblk), dim3(64), 0, ctx->stream, vp.V, (int)n,
+                       static_cast<double*>(cbuf));
+    hipLaunchKernelGGL(symeig_vectors_kernel<256>, dim3((unsigned)k), dim3(64), vlds, ctx->stream, vp);
   } else {
     const size_t vlds = sizeof(double) * (8 * 512 + 8) + 512;
     hipLaunchKernelGGL(symeig_wy_kernel<512>, dim3((unsigned)nblk), dim3(64), 0, ctx->stream, vp.V, (int)n,
