@@ -653,7 +653,9 @@ extern "C" int rt_sym_eig_values_part(rt_ctx* ctx, const double* G, int64_t n, i
   // A ctx confined to few CUs (CU-masked stream of the POD pipeline, "cu_limit") halves the team for n <= 512: 16
   // workgroups hold 32 rows each (147 KB of LDS); a column then costs more mat-vec but the same hand-off.
   const bool small_team = !large && ctx->num_cus < TW_SMALL && ctx->num_cus >= TW_SMALL / 2;
-  const int tw = large ? TW_LARGE : (small_team ? TW_SMALL / 2 : TW_SMALL);
+  static const int tw_env = [] { const char* e = getenv("ROMTIME_EIG_TW"); return e ? atoi(e) : 0; }();   // measurement switch
+  int tw = large ? TW_LARGE : (small_team ? TW_SMALL / 2 : TW_SMALL);
+  if (!large && tw_env >= 1 && tw_env <= TW_SMALL && (long)((n + tw_env - 1) / tw_env) * n * 8 <= 120 * 1024) tw = tw_env;
   if (tw > ctx->num_cus) {  // the cooperating workgroups must all be resident
     ctx->err = "rt_sym_eig_values: not enough compute units for the cooperative tridiagonalisation";
     return RT_ERR_UNSUPPORTED;

@@ -549,7 +549,7 @@ class PodWorkers:
         with torch.cuda.stream(st):
             st.wait_event(ready)                       # the set was produced on the caller's stream
             n = X.shape[1]
-            if 3 <= n <= 1024:
+            if 3 <= n <= 1024 and X.numel() < SMALL_SET:
                 # the composite C entry point: the whole POD (truncation rule, deflated levels, Rayleigh-Ritz) in ONE
                 # foreign call, during which the interpreter lock is released - the worker threads then really run side
                 # by side (with pod.pod_device the Python between a deep POD's kernels serialised them: 1.3x for eight)
@@ -557,6 +557,9 @@ class PodWorkers:
                 out = dict(Q=Q, s=s, energy=energy, VT=None, r=int(Q.shape[1]), passes=1 if levels <= 1 else "deflate",
                            levels=levels, colnorm=None)
             else:
+                # wider than the composite takes, or a LARGE set: pod_device allocates the basis only once the spectrum
+                # has fixed its width (the composite wants room for every column up front - as much again as the set -
+                # and eight of those in flight is not what 4 GB sets should cost); such sets are device-bound anyway
                 out = pod.pod_device(X, **kwargs)
             done = torch.cuda.Event()
             done.record(st)
