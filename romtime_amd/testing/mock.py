@@ -209,11 +209,62 @@ class MockHeatEquation(MockSolver):
     def assemble_rhs(self, mu, t, entries=None):
         return self.assemble_forcing(mu, t, entries) + self.assemble_lifting(mu, t, entries)   # fom/heat.py:171-188
 
+    def mesh_velocity_amplitude(self, mu, t):
+        """w(L): the mesh velocity of the ALE form is the ramp w(x) = x dLt_dt / Lt (fom/heat.py:242-249)."""
+        if self.dLt_dt is None:
+            return 0.0
+        return self._L(mu, t) * self.dLt_dt(t=t, **mu) / self.Lt(t=t, **mu)
+
+    def assemble_convection(self, mu=None, t=None, entries=None):
+        """The ALE term  -int w u' v  (fom/heat.py:267-285): w is linear, so its nodal interpolant is exact and the
+        element matrices are those of the trilinear form with w as the state, negated.  Zero on a fixed mesh (where
+        the reference's fixed-mesh solver has no such operator at all)."""
+        w = self.mesh_velocity_amplitude(mu, t) * np.arange(self.Nh) / self.nx
+        wa, wb = w[:-1], w[1:]
+        a, b = (2.0 * wa + wb) / 6.0, (wa + 2.0 * wb) / 6.0
+        elem = -np.stack([np.stack([-a, a], axis=1), np.stack([-b, b], axis=1)], axis=1)
+        return self._assemble_matrix(elem, entries)
+
+    def assemble_system(self, mu, t):
+        """(M, K) of a BDF1 step, K = M + dt (C + A) (fom/heat.py:57-82 fixed, :251-262 moving)."""
+        M = self.assemble_mass(mu, t)
+        K = M + self.dt * (self.assemble_stiffness(mu, t) + self.assemble_convection(mu, t))
+        return M, K
+
+    def solve(self):
+        """Full-order BDF1 time loop (host, SciPy sparse LU) producing ``solutions`` the way
+        ``OneDimensionalSolver.solve`` does (fom/base.py:693-831): zero initial condition (u0 = 0 and g(0) = 0 for this
+        problem), ``snapshots`` hold the homogeneous part, ``fom`` adds the lifting function on the moved mesh."""
+        from scipy.sparse.linalg import spsolve
+
+        from ..storage import SolutionsStorage
+
+        mu, dt = self.mu, self.dt
+        u = np.zeros(self.Nh)
+        ts, homog, full, xs = [], [], [], []
+        self.errors = []
+        for step in range(int(self.domain["nt"])):
+            t = (step + 1) * dt
+            M, K = self.assemble_system(mu, t)
+            rhs = M.dot(u) + dt * self.assemble_rhs(mu, t)                  # fom/heat.py:57-67
+            rhs[0] = rhs[-1] = 0.0
+            u = spsolve(K.tocsc(), rhs)
+            ts.append(t)
+            homog.append(u.copy())
+            full.append(u + self.lifting(mu, t))
+            xs.append(self.x_at(mu, t).reshape(-1, 1))
+            self.errors.append(float(np.sqrt(np.mean((full[-1] - self.exact_solution_at(mu, t)) ** 2))))
+        self.solutions = SolutionsStorage(ts=ts, mu=mu, domain=np.hstack(xs), fom=np.array(full).T,
+                                          snapshots=np.array(homog).T)
+        self.nonlinear_snapshots = None
+
     def p1_closed_form(self, mus, ts):
         """As MockSolver.p1_closed_form, plus what ``rt_p1_local_assembly("load_p2", poly=...)`` needs for the two load
-        vectors: (nt, n_mu, 3) polynomial coefficients of the forcing and of dg_dt."""
+        vectors: (nt, n_mu, 3) polynomial coefficients of the forcing and of dg_dt; and ``mesh_velocity`` (nt, n_mu): the
+        amplitude of the ramp w of the ALE convection operator = minus the trilinear kind with that ramp."""
         out = _p1_closed_form(self, mus, ts)
         out["alpha"] = np.broadcast_to(np.array([mu["alpha_0"] for mu in mus])[None, :], out["h"].shape).copy()
+        out["mesh_velocity"] = np.array([[self.mesh_velocity_amplitude(mu, t) for mu in mus] for t in np.asarray(ts, dtype=float)])
         out["forcing_poly"] = np.array([[self.forcing_poly(mu, t) for mu in mus] for t in np.asarray(ts, dtype=float)])
         out["lifting_poly"] = np.array([[self.lifting_poly(mu, t) for mu in mus] for t in np.asarray(ts, dtype=float)])
         return out

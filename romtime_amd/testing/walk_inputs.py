@@ -116,3 +116,25 @@ def piston_grid():
     from scipy.stats.distributions import uniform
 
     return {"a0": uniform(10.0, 10.0), "omega": uniform(8.0, 4.0), "delta": uniform(0.2, 0.3), "alpha_0": uniform(0.04, 0.08)}
+
+
+def heat_problem(moving, nx=160, nt=40, r=9):
+    """Config 1's problem - the manufactured heat equation MFP1 (problems/mfp1.py:19-75) on a fixed or moving interval -
+    with a fixed orthonormal trial basis (low sine modes, homogeneous at the Dirichlet ends) and the (mu, t) states at
+    which tests/golden/make_golden.py::gen_heat records the reference's reduced operators.  Returns (fom, V, states)."""
+    from .mock import MockHeatEquation
+
+    kw = {}
+    if moving:
+        kw = dict(Lt=lambda t, **mu: 1.0 - 0.25 * np.sin(mu["omega"] * t),
+                  dLt_dt=lambda t, **mu: -0.25 * mu["omega"] * np.cos(mu["omega"] * t))
+    fom = MockHeatEquation(domain=dict(L0=2.0, nx=nx, T=1.0, nt=nt), **kw)
+    fom.setup()
+    rng = np.random.RandomState(7)
+    x = np.linspace(0.0, 1.0, fom.Nh)
+    modes = np.array([np.sin((k + 1) * np.pi * x) for k in range(r)]).T + 1e-3 * rng.standard_normal((fom.Nh, r))
+    modes[0, :] = modes[-1, :] = 0.0
+    V, _ = np.linalg.qr(modes)
+    states = [(dict(delta=0.4 + 0.3 * q, beta=2.0 + 1.5 * q, alpha_0=0.3 + 0.25 * q, omega=1.0 + q), 0.05 + 0.21 * q)
+              for q in range(4)]
+    return fom, V, states

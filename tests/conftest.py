@@ -34,6 +34,11 @@ def golden_rom():
 
 
 @pytest.fixture(scope="session")
+def golden_heat():
+    return load_golden("heat.npz")
+
+
+@pytest.fixture(scope="session")
 def golden_sampler():
     return load_golden("sampler.npz")
 

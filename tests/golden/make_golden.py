@@ -819,6 +819,55 @@ def gen_hrom(ref, out):
             print("  ", which, idx, {k: float(np.max(v)) for k, v in payload.items()})
 
 
+class HeatFomAdapter(RefFomAdapter):
+    """Presents the closed-form MFP1 heat problem (romtime_amd.testing.mock.MockHeatEquation) to the reference's linear
+    ROM classes: dolfin-like Matrix / Vector stand-ins around its operators and load vectors."""
+
+    def assemble_forcing(self, mu, t):
+        return self._ref.Vector(self._fom.assemble_forcing(mu, t))
+
+
+def gen_heat(ref, out):
+    """The reference's LINEAR ROM classes (rom.py:34-736) on the heat problem of config 1, fixed and moving mesh.
+    At v0 their `solve` cannot run (it calls assemble_system / assemble_system_rhs with the argument lists of the
+    nonlinear class, rom.py:487-488 vs :557-573, :714-736: TypeError), so the fixture pins what CAN run - every reduced
+    operator and vector, and the reference's own K_N and b_N formulas - at several (mu, t)."""
+    from romtime_amd.testing.mock import MockHeatEquation
+    from romtime_amd.testing.walk_inputs import heat_problem
+
+    rng = np.random.RandomState(20260110)
+    data = {}
+    cases = []
+    for moving in (False, True):
+        fom, V, states = heat_problem(moving)
+        ad = HeatFomAdapter(ref, fom)
+        cls = ref.rom.RomConstructorMoving if moving else ref.rom.RomConstructor
+        rom = cls(fom=ad, grid=None, name="golden-heat")
+        rom.setup(rnd=0)
+        rom.basis = V
+        key = "moving" if moving else "fixed"
+        cases.append(key)
+        data[f"V__{key}"] = V
+        for q, (mu, t) in enumerate(states):
+            uN = rng.standard_normal(V.shape[1])
+            MN, KN = rom.assemble_system(mu, t)                       # rom.py:565-573 / :714-736
+            bN = rom.assemble_system_rhs(mu, t, uN, MN)               # rom.py:557-563 (argument order of the base class)
+            tag = f"{key}_{q}"
+            data[f"uN__{tag}"] = uN
+            data[f"MN__{tag}"], data[f"KN__{tag}"], data[f"bN__{tag}"] = MN, KN, bN
+            data[f"AN__{tag}"] = rom.assemble_stiffness(mu, t)
+            data[f"fN__{tag}"] = rom.assemble_forcing(mu, t)
+            data[f"fgN__{tag}"] = rom.assemble_lifting(mu, t)
+            data[f"rhsN__{tag}"] = rom.assemble_rhs(mu, t)
+            if moving:
+                data[f"CN__{tag}"] = rom.assemble_convection(mu, t)
+        data[f"n_states__{key}"] = np.array(len(states))
+    data["cases"] = np.array(cases)
+    data["versions"] = np.array(repr(_versions()))
+    np.savez_compressed(os.path.join(out, "heat.npz"), **data)
+    print("heat.npz:", cases, {k: int(data[f"n_states__{k}"]) for k in cases})
+
+
 def main():
     if not os.path.isdir(REF):
         print("reference not present; nothing to do")
@@ -830,6 +879,7 @@ def main():
     gen_sampler(ref, HERE)
     gen_walks(ref, HERE)
     gen_hrom(ref, HERE)
+    gen_heat(ref, HERE)
 
 
 if __name__ == "__main__":

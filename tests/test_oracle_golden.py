@@ -235,6 +235,56 @@ def test_heat_problem_mock_converges_to_its_exact_solution():
     assert e2 < 0.6 * e1 and e3 < 0.6 * e2 and e3 < 1e-3        # first order in time, nothing left over
 
 
+def test_moving_mesh_heat_problem_mock_converges_to_its_exact_solution():
+    """The same problem on a MOVING interval (config 1): the ALE convection operator -int w u' v with the mesh velocity
+    w = x dL/dt / L (fom/heat.py:242-285), the moving-boundary term of dg_dt (fom/base.py:413-421) and the data
+    evaluated on the moved mesh are all live; BDF1 as fom/heat.py:251-262 forms it.  First order in dt to the exact
+    solution - any inconsistent piece leaves an O(1) error."""
+    from romtime_amd.testing.mock import MockHeatEquation
+
+    mu = dict(delta=1.0, beta=5.0, alpha_0=1.0, omega=2.0)
+    Lt = lambda t, **m: 1.0 - 0.3 * np.sin(m["omega"] * t)
+    dLt = lambda t, **m: -0.3 * m["omega"] * np.cos(m["omega"] * t)
+    errs = []
+    for nt in (200, 400, 800):
+        fom = MockHeatEquation(domain={"L0": 2.0, "nx": 40, "T": 1.0, "nt": nt}, Lt=Lt, dLt_dt=dLt)
+        fom.setup()
+        fom.update_parametrization(mu)
+        fom.solve()
+        errs.append(max(fom.errors))                       # measured: 5.4e-3, 2.6e-3, 1.3e-3 (rms over the mesh)
+    assert errs[1] < 0.6 * errs[0] and errs[2] < 0.6 * errs[1] and errs[2] < 2e-3
+    fixed = MockHeatEquation(domain={"L0": 2.0, "nx": 40, "T": 1.0, "nt": 400})
+    fixed.setup()
+    assert np.abs(fixed.assemble_convection(mu, 0.3).toarray()[1:-1]).max() == 0.0      # no mesh motion, no ALE term
+
+
+def test_oracle_reduced_operators_of_the_heat_problem_match_the_reference_classes(golden_heat):
+    """heat.npz = the reference's RomConstructor / RomConstructorMoving methods (rom.py:557-736) run on the heat mock:
+    the oracle's projections and its K_N / b_N formulas reproduce them."""
+    from romtime_amd.testing.walk_inputs import heat_problem
+
+    g = golden_heat
+    for key in g["cases"]:
+        moving = str(key) == "moving"
+        fom, V, states = heat_problem(moving)
+        np.testing.assert_allclose(V, g[f"V__{key}"], rtol=0, atol=1e-14)
+        for q, (mu, t) in enumerate(states):
+            tag = f"{key}_{q}"
+            MN = oracle.project_csr(fom.assemble_mass(mu, t), V)
+            AN = oracle.project_csr(fom.assemble_stiffness(mu, t), V)
+            CN = oracle.project_csr(fom.assemble_convection(mu, t), V) if moving else 0.0 * AN
+            fN = V.T @ fom.assemble_forcing(mu, t) + V.T @ fom.assemble_lifting(mu, t)
+            KN = oracle.assemble_system(MN, AN, CN, 0.0, 0.0, 1.0, fom.dt)
+            bN = oracle.assemble_system_rhs(MN, fN, g[f"uN__{tag}"], None, fom.dt)
+            scale = np.abs(g[f"KN__{tag}"]).max()
+            np.testing.assert_allclose(MN, g[f"MN__{tag}"], rtol=0, atol=1e-14 * scale)
+            np.testing.assert_allclose(KN, g[f"KN__{tag}"], rtol=0, atol=1e-14 * scale)
+            np.testing.assert_allclose(fN, g[f"rhsN__{tag}"], rtol=0, atol=1e-14 * np.abs(g[f"rhsN__{tag}"]).max())
+            np.testing.assert_allclose(bN, g[f"bN__{tag}"], rtol=0, atol=1e-14 * np.abs(g[f"bN__{tag}"]).max())
+            if moving:
+                np.testing.assert_allclose(CN, g[f"CN__{tag}"], rtol=0, atol=1e-14 * np.abs(g[f"CN__{tag}"]).max())
+
+
 def test_closed_form_moving_mesh_stiffness_matches_the_reference_table():
     """tests/test_moving_mesh.py:102-150: stiffness of the moving-mesh solver (nx = 5, L(t) = 1 + sin(omega t),
     alpha_0 = 0.5) at t = 0 and t = 5; the reference's CSR keeps two explicit zeros in the Dirichlet rows, which

@@ -161,3 +161,29 @@ def test_degree2_load_vectors_on_the_device():
             d0, d1, _ = cf["lifting_poly"][it, j]
             scale = cf["h"][it, j] * (abs(d0) + abs(d1) * cf["h"][it, j] * nx) + abs(mu["alpha_0"] * mov.boundary_data(mu, t)["grad_g"])
             np.testing.assert_allclose(G[it * len(mus) + j], ref_g, rtol=1e-12, atol=4 * np.finfo(float).eps * scale)
+
+
+def test_ale_convection_of_the_moving_heat_problem_on_the_device():
+    """-int w u' v with the mesh velocity w = x dL/dt / L (fom/heat.py:242-285) is minus the trilinear kind with the
+    ramp amplitude w(L): device table against the NumPy closed form (MockHeatEquation.assemble_convection), many states."""
+    from romtime_amd import ops
+    from romtime_amd.testing.mock import MockHeatEquation
+
+    nx = 300
+    mov = MockHeatEquation(domain={"L0": 1.2, "nx": nx, "T": 1.0, "nt": 25}, Lt=lambda t, **mu: 1.0 - 0.3 * np.sin(mu["omega"] * t),
+                           dLt_dt=lambda t, **mu: -0.3 * mu["omega"] * np.cos(mu["omega"] * t))
+    mov.setup()
+    mus = [dict(delta=0.5, beta=2.0, alpha_0=0.4, omega=1.0 + q) for q in range(3)]
+    ts = mov.dt * np.arange(1, 26)
+    cf = mov.p1_closed_form(mus, ts)
+    rows, cols = _pattern(nx)
+    flat = lambda a: a.reshape(-1)
+    C = ops.p1_local_assembly("trilinear", nx, rows, cols, flat(cf["h"]), coef=-np.ones(ts.size * len(mus)),
+                              ramp=flat(cf["mesh_velocity"])).cpu().numpy()
+    entries = list(zip(rows.tolist(), cols.tolist()))
+    for it, t in enumerate(ts):
+        for j, mu in enumerate(mus):
+            ref = mov.assemble_convection(mu, t, entries=entries)
+            got = C[it * len(mus) + j]
+            # the Dirichlet rows of a matrix kind are identity rows on both sides (coef does not touch them)
+            np.testing.assert_allclose(got, ref, rtol=1e-12, atol=1e-14 * np.abs(ref).max())

@@ -338,6 +338,60 @@ def check_to_rom_roundtrip():
     assert rom.N == 9 and rom.shape == V.shape
 
 
+def check_linear_rom_classes_on_the_heat_problem(golden_heat):
+    """RomConstructor / RomConstructorMoving (rom.py:34-736) on config 1's problem, the manufactured heat equation on a
+    fixed and a moving interval (testing.mock.MockHeatEquation), against the reference's OWN classes run on the same
+    FOM (tests/golden/heat.npz: every reduced operator and vector, K_N = M_N + dt (A_N [+ C_N]) and
+    b_N = M_N u_N + dt f_N as rom.py:557-573, 714-736 form them).  The reference's `solve` cannot run for these two
+    classes at v0 (argument lists of the nonlinear class at the call sites, rom.py:487-488), so the time loop is
+    checked end to end instead: reduced basis from three parameters, online solve for a fourth, against the FOM's own
+    run and the problem's exact solution."""
+    from romtime_amd import RomConstructor, RomConstructorMoving
+    from romtime_amd.conventions import RomParameters, Stage
+    from romtime_amd.testing.walk_inputs import heat_problem
+
+    g = golden_heat
+    for key in g["cases"]:
+        moving = str(key) == "moving"
+        fom, V, states = heat_problem(moving)
+        assert_allclose(V, g[f"V__{key}"], rtol=0, atol=1e-14)
+        rom = (RomConstructorMoving if moving else RomConstructor)(fom=fom, grid=None)
+        rom.setup(rnd=0)
+        rom.basis = g[f"V__{key}"]
+        assert int(g[f"n_states__{key}"]) == len(states)
+        for q, (mu, t) in enumerate(states):
+            tag = f"{key}_{q}"
+            scale = np.abs(g[f"KN__{tag}"]).max()
+            MN, KN = rom.assemble_system(mu, t)
+            assert_allclose(MN, g[f"MN__{tag}"], rtol=0, atol=1e-13 * scale)
+            assert_allclose(KN, g[f"KN__{tag}"], rtol=0, atol=1e-13 * scale)
+            assert_allclose(rom.assemble_stiffness(mu, t), g[f"AN__{tag}"], rtol=0, atol=1e-13 * np.abs(g[f"AN__{tag}"]).max())
+            for name, fn in (("fN", rom.assemble_forcing), ("fgN", rom.assemble_lifting), ("rhsN", rom.assemble_rhs)):
+                ref = g[f"{name}__{tag}"]
+                assert_allclose(fn(mu, t), ref, rtol=0, atol=1e-13 * max(np.abs(ref).max(), 1e-300), err_msg=name)
+            bN = rom.assemble_system_rhs(mu, t, MN, g[f"uN__{tag}"])          # the call-site order (rom.py:488)
+            assert_allclose(np.asarray(bN), g[f"bN__{tag}"], rtol=0, atol=1e-13 * np.abs(g[f"bN__{tag}"]).max())
+            if moving:
+                ref = g[f"CN__{tag}"]
+                assert_allclose(rom.assemble_convection(mu, t), ref, rtol=0, atol=1e-13 * np.abs(ref).max())
+        # the time loop: offline on three parameters, online on a fourth
+        fom2, _, _ = heat_problem(moving, nx=120, nt=60)
+        rom = (RomConstructorMoving if moving else RomConstructor)(fom=fom2, grid=None)
+        rom.setup(rnd=0)
+        train = [dict(delta=0.5 + 0.4 * i, beta=3.0 + 2.0 * i, alpha_0=0.5 + 0.3 * i, omega=1.0 + 0.7 * i) for i in range(3)]
+        rom.build_reduced_basis(mu_space=train, tolerances={RomParameters.TOL_TIME: 1.0 - 1e-12, RomParameters.TOL_MU: 1.0 - 1e-12})
+        assert 3 <= rom.N <= 40
+        mu = dict(delta=0.8, beta=4.5, alpha_0=0.7, omega=1.5)
+        fom2.update_parametrization(mu)
+        fom2.solve()
+        truth = fom2.solutions.fom.copy()
+        rom.solve(mu=mu, step=Stage.ONLINE)
+        err = np.linalg.norm(rom.solutions.fom - truth) / np.linalg.norm(truth)
+        assert err < 5e-4, (key, err, rom.N)                       # the basis reproduces an unseen parameter's FOM run
+        exact = np.array([fom2.exact_solution_at(mu, t) for t in fom2.solutions.ts]).T
+        assert np.abs(rom.solutions.fom - exact).max() < 10 * max(fom2.errors) + 1e-3
+
+
 def check_artefact_round_trip(golden_deim, tmp_path, monkeypatch):
     """On-disk artefacts keep the reference's names and payloads (deim.py:77-81,166-173; conventions.py:4-12;
     hrom.py:151-166): a basis dumped by one reductor is adopted by a fresh one under the same name, and the
@@ -421,6 +475,10 @@ def test_artefact_round_trip_hostlogic(cpu_ops, golden_deim, tmp_path, monkeypat
     check_artefact_round_trip(golden_deim, tmp_path, monkeypatch)
 
 
+def test_linear_rom_classes_heat_hostlogic(cpu_ops, golden_heat):
+    check_linear_rom_classes_on_the_heat_problem(golden_heat)
+
+
 def test_product_path_fails_loudly_without_gpu():
     """No silent CPU fallback: on a box without a GPU the hot path raises."""
     import torch
@@ -480,6 +538,11 @@ def test_to_rom_hip():
 @pytest.mark.gpu
 def test_hyper_reduced_loop_hip():
     check_hyper_reduced_loop_matches_oracle(device_sweep=True)
+
+
+@pytest.mark.gpu
+def test_linear_rom_classes_heat_hip(golden_heat):
+    check_linear_rom_classes_on_the_heat_problem(golden_heat)
 
 
 @pytest.mark.gpu
