@@ -362,15 +362,16 @@ def check_linear_rom_classes_on_the_heat_problem(golden_heat):
         for q, (mu, t) in enumerate(states):
             tag = f"{key}_{q}"
             scale = np.abs(g[f"KN__{tag}"]).max()
-            MN, KN = rom.assemble_system(mu, t)
-            assert_allclose(MN, g[f"MN__{tag}"], rtol=0, atol=1e-13 * scale)
-            assert_allclose(KN, g[f"KN__{tag}"], rtol=0, atol=1e-13 * scale)
+            host = lambda a: a.detach().cpu().numpy() if hasattr(a, "detach") else np.asarray(a)
+            MN, KN = rom.assemble_system(mu, t)        # device tensors here: `solve` keeps the step's r x r algebra in HBM
+            assert_allclose(host(MN), g[f"MN__{tag}"], rtol=0, atol=1e-13 * scale)
+            assert_allclose(host(KN), g[f"KN__{tag}"], rtol=0, atol=1e-13 * scale)
             assert_allclose(rom.assemble_stiffness(mu, t), g[f"AN__{tag}"], rtol=0, atol=1e-13 * np.abs(g[f"AN__{tag}"]).max())
             for name, fn in (("fN", rom.assemble_forcing), ("fgN", rom.assemble_lifting), ("rhsN", rom.assemble_rhs)):
                 ref = g[f"{name}__{tag}"]
                 assert_allclose(fn(mu, t), ref, rtol=0, atol=1e-13 * max(np.abs(ref).max(), 1e-300), err_msg=name)
             bN = rom.assemble_system_rhs(mu, t, MN, g[f"uN__{tag}"])          # the call-site order (rom.py:488)
-            assert_allclose(np.asarray(bN), g[f"bN__{tag}"], rtol=0, atol=1e-13 * np.abs(g[f"bN__{tag}"]).max())
+            assert_allclose(host(bN), g[f"bN__{tag}"], rtol=0, atol=1e-13 * np.abs(g[f"bN__{tag}"]).max())
             if moving:
                 ref = g[f"CN__{tag}"]
                 assert_allclose(rom.assemble_convection(mu, t), ref, rtol=0, atol=1e-13 * np.abs(ref).max())
