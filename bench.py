@@ -511,7 +511,10 @@ def main():
                                                                  if pipe_mode else achieved / FP64_MFMA_PEAK_TFLOPS),
                         algorithmic_flops=alg_flops, algorithmic_bytes=alg_bytes,
                         hbm_frac=alg_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        note="FP64 Gram at n=512 is 64 flop/B: matrix-core bound, not HBM bound")
+                        note="FP64 Gram at n=512 is 64 flop/B: matrix-core bound, not HBM bound.  peak = the spec figure "
+                             "(2.4 GHz x 32 flop/clk/SIMD); this part sustains 47-48 TF on FP64 MFMAs alone with the pipe "
+                             "saturated (profiles/r03_mfma_sustained.txt) and 66.7 TF in this kernel on all-zero data: "
+                             "the kernel runs at the board's power limit")
         line = base_line(args, world, n_local, value, ms_per_step, out["passes"], mode, latency_ms)
         line["stage_ms"] = {k: round(v, 4) for k, v in stage_ms.items()}
         line["roofline"] = roofline
