@@ -47,6 +47,7 @@ struct TriParams {
   int* flags;        // [3] = error, [4] = worker tickets of the one-XCD form, [8 .. 8 + tw) = XCC id of each workgroup, [SLOT0 .. SLOT0 + tw) = arrival slots
   int n;
   int tw;            // cooperating workgroups
+  int local;         // 1: ONE workgroup holds the whole matrix (n <= 128): p and the next row never leave its LDS
   int spread;        // 1: launched as 8 tw blocks, only the blocks with blockIdx % 8 == xcd work (they share an XCD)
   int xcd;
   long* counters;    // rt_ctx::dev_counters: which hand-off form ran, and time-outs (rt_ctx_get_counter)
@@ -133,17 +134,22 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
   const int n = p.n, TW = p.tw, tid = threadIdx.x, wg = p.spread ? s_ticket : blockIdx.x, lane = tid & 63,
             wid = tid >> 6;
   const int RB = (n + TW - 1) / TW;
-  double* A = sm;                 // RB x n, local row li <-> global row li*TW + wg
-  double* svb = sm + (size_t)RB * n;  // v, double buffered by step parity (2 x n)
+  const bool local = p.local != 0;   // wave-uniform: tw == 1, every row is this workgroup's
+  // local form: eight lanes share a row (see the mat-vec), so eight rows are read at once - two words of padding per row
+  // spread them over the banks
+  const int lda = local ? n + 2 : n;
+  double* A = sm;                 // RB x lda, local row li <-> global row li*TW + wg
+  double* svb = sm + (size_t)RB * lda;  // v, double buffered by step parity (2 x n)
   double* sw = svb + 2 * n;
   double* sl = sw + n;            // current row k (entries j >= k), maintained by wave 0
+  double* sP = sl + n;            // local form only: p = tau A v (the host sizes the LDS for it)
   __shared__ int s_abort;
   if (threadIdx.x == 0) s_abort = 0;
   constexpr int PER = NM / 64;
 
   for (int q = tid; q < RB * n; q += TT) {
     const int li = q / n, j = q % n, gi = li * TW + wg;
-    A[q] = (gi < n) ? p.G[(size_t)gi * n + j] : 0.0;
+    A[(size_t)li * lda + j] = (gi < n) ? p.G[(size_t)gi * n + j] : 0.0;
   }
   __syncthreads();
   const int ty = tid / LPR, tx = tid % LPR;  // (TT / LPR) rows x LPR lanes; with LPR = 64: ty == wave id
@@ -153,6 +159,19 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
   // P = [p even | p odd | row even | row odd].  Row 0 travels in the ODD row buffer: step 0 stores into the even
   // one, and a workgroup may get there before a slow one has read row 0.
   double* L0 = p.P + (size_t)3 * n;
+  __shared__ int s_one;
+  if (local) {
+    // Round 3: a Gram matrix of up to 128 columns fits ONE workgroup's LDS.  A column then needs no hand-off at all -
+    // no payload stores to drain, no arrival slot, no poll, no payload loads: each of those is a memory round trip of
+    // 0.5-0.7 us that the cooperative form pays even when the "team" is a single workgroup (3.3 us per column at n = 64
+    // whatever the team size).  p goes through LDS (sP), the next row is read where it lies.
+    for (int j = tid; j < n; j += TT) sl[j] = A[j];
+    if (tid == 0) {
+      s_one = 0;
+      atomicAdd(reinterpret_cast<unsigned long long*>(&p.counters[RT_CNT_EIG_ONE_XCD]), 1ull);
+    }
+    __syncthreads();
+  } else {
   if (wg == 0)
     for (int j = tid; j < n; j += TT) st_wt(&L0[j], A[j]);
   if (tid == 0)  // where this workgroup runs: HW_REG_XCC_ID[3:0]
@@ -169,7 +188,6 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
   if (s_abort) return;
   for (int j = tid; j < n; j += TT) sl[j] = ld_wt(&L0[j]);
   // every workgroup reads the same TW ids and takes the same decision; the placement is observed, not assumed
-  __shared__ int s_one;
   if (tid == 0) {
     const int mine = __hip_atomic_load(&p.flags[8], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     int same = (p.spread != 0) && (mine > 0);
@@ -179,6 +197,7 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
     if (wg == 0) atomicAdd(reinterpret_cast<unsigned long long*>(&p.counters[same ? RT_CNT_EIG_ONE_XCD : RT_CNT_EIG_GENERAL_FORM]), 1ull);
   }
   __syncthreads();
+  }  // !local
   const bool one_xcd = s_one != 0;
 
   __shared__ double s_tauv[2];  // tau of step k in s_tauv[k & 1]
@@ -258,6 +277,20 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
     // ---- p = tau * A v on the local rows i > k; the wave that holds row k+1 adds that row (pre-update) ----
     double* Pk = p.P + (size_t)(k & 1) * n;
     double* Lk = p.P + (size_t)(2 + (k & 1)) * n;
+    if (local) {
+      // 128 rows x 8 lanes: every row of the matrix is reduced at once (a wave per row took n / 16 rounds of a 64-lane
+      // DPP sum one after the other: the mat-vec, not the hand-off, would be the column's time here)
+      const int gi = tid >> 3, sub = tid & 7;
+      double acc = 0.0;
+      if (tau != 0.0 && gi > k && gi < n) {
+        const double* row = A + (size_t)gi * lda;
+        for (int j = k + 1 + sub; j < n; j += 8) acc = fma(row[j], sv[j], acc);
+      }
+      acc += __shfl_xor(acc, 1);
+      acc += __shfl_xor(acc, 2);
+      acc += __shfl_xor(acc, 4);
+      if (sub == 0 && tau != 0.0 && gi > k && gi < n) sP[gi] = tau * acc;
+    } else
     for (int li = ty; li < RB; li += TT / LPR) {
       const int gi = li * TW + wg;
       if (gi > k && gi < n) {
@@ -266,36 +299,45 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
           double acc = 0.0;
           for (int j = k + 1 + tx; j < n; j += LPR) acc = fma(row[j], sv[j], acc);
           acc = rtw::wave_sum(acc);
-          if (tx == 0) st_xcd(&Pk[gi], tau * acc, one_xcd);
+          if (tx == 0) {
+            if (local) sP[gi] = tau * acc;
+            else st_xcd(&Pk[gi], tau * acc, one_xcd);
+          }
         }
-        if (gi == k + 1)
+        if (gi == k + 1 && !local)
           for (int j = k + 1 + tx; j < n; j += LPR) st_xcd(&Lk[j], row[j], one_xcd);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (!local) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // B2
     // the hop numbers only grow: nobody can arrive for hop h+1 before all arrived for hop h, and the payload
     // buffers alternate, so a fast workgroup never overwrites what a slow one still reads.  Wave 0 arrives, waits
     // and goes straight on to the payload; the other waves meet it again at B5.
     ++hop;
     if (wid == 0) {
-      if (lane == 0) st_slot(&p.flags[SLOT0 + wg], hop, one_xcd);
+      if (lane == 0 && !local) st_slot(&p.flags[SLOT0 + wg], hop, one_xcd);
       double v[PER];  // this step's reflector, element j = k + 1 + lane + 64 q (LDS read in flight during the poll)
 #pragma unroll
       for (int q = 0; q < PER; ++q) {
         const int j = k + 1 + lane + 64 * q;
         v[q] = (j < n) ? sv[j] : 0.0;
       }
-      if (!poll_slots(&p.flags[SLOT0], TW, hop, &p.flags[3])) {
+      if (!local && !poll_slots(&p.flags[SLOT0], TW, hop, &p.flags[3])) {
         if (lane == 0) s_abort = 1;
       } else {
         // wave 0 takes p and the next row straight into registers
         double pv[PER], x[PER];
+        const double* nextrow = A + (size_t)(k + 1) * lda;   // local form: row k + 1 as it stands, pre-update
 #pragma unroll
         for (int q = 0; q < PER; ++q) {
           const int j = k + 1 + lane + 64 * q;
-          x[q] = (j < n) ? ld_wt(&Lk[j]) : 0.0;
-          pv[q] = (j < n && tau != 0.0) ? ld_wt(&Pk[j]) : 0.0;
+          if (local) {
+            x[q] = (j < n) ? nextrow[j] : 0.0;
+            pv[q] = (j < n && tau != 0.0) ? sP[j] : 0.0;
+          } else {
+            x[q] = (j < n) ? ld_wt(&Lk[j]) : 0.0;
+            pv[q] = (j < n && tau != 0.0) ? ld_wt(&Pk[j]) : 0.0;
+          }
         }
         if (tau != 0.0) {
           double dot = 0.0;
@@ -326,6 +368,14 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
     if (s_abort) return;
     if (tau == 0.0) continue;
     // ---- A <- A - v w^T - w v^T on the local rows i > k (each wave touches only the rows it also reads) ----
+    if (local) {
+      const int gi = tid >> 3, sub = tid & 7;
+      if (gi > k && gi < n) {
+        double* row = A + (size_t)gi * lda;
+        const double vi = sv[gi], wi = sw[gi];
+        for (int j = k + 1 + sub; j < n; j += 8) row[j] -= vi * sw[j] + wi * sv[j];
+      }
+    } else
     for (int li = ty; li < RB; li += TT / LPR) {
       const int gi = li * TW + wg;
       if (gi > k && gi < n) {
@@ -342,7 +392,7 @@ __global__ __launch_bounds__(TT) void symeig_tridiag_kernel(const TriParams p) {
     p.e[n - 2] = sl[n - 1];
   }
   if (wg == (n - 1) % TW && tid == 0) {
-    p.d[n - 1] = A[(size_t)((n - 1) / TW) * n + (n - 1)];
+    p.d[n - 1] = A[(size_t)((n - 1) / TW) * lda + (n - 1)];
     p.e[n - 1] = 0.0;
   }
 }
@@ -656,6 +706,14 @@ extern "C" int rt_sym_eig_values_part(rt_ctx* ctx, const double* G, int64_t n, i
   static const int tw_env = [] { const char* e = getenv("ROMTIME_EIG_TW"); return e ? atoi(e) : 0; }();   // measurement switch
   int tw = large ? TW_LARGE : (small_team ? TW_SMALL / 2 : TW_SMALL);
   if (!large && tw_env >= 1 && tw_env <= TW_SMALL && (long)((n + tw_env - 1) / tw_env) * n * 8 <= 120 * 1024) tw = tw_env;
+  // One workgroup holds the whole matrix: no hand-offs (see the kernel).  Measured (tools/probes/eig_tw_ab.py, values + 40
+  // vectors): n = 16 / 33 / 64: 0.076 / 0.120 / 0.211 ms against 0.091 / 0.140 / 0.233 in the cooperative form - but
+  // n = 128: 0.50 against 0.44: the hand-off is NOT what a column costs at these sizes (nor does the team size matter:
+  // 32, 16, 8, 2 or 1 workgroups give the same 3.3 us per column); it is the three barriers of a 1024-thread workgroup and
+  // wave 0's serial sections, and with all 128 rows in one workgroup those get longer.  ROMTIME_EIG_FLAGS & 8 extends the
+  // form to n <= 128 for measurements.
+  const bool local = (n <= 64 || ((eig_flags & 8) && n <= 128)) && !(eig_flags & 4);
+  if (local) tw = 1;
   if (tw > ctx->num_cus) {  // the cooperating workgroups must all be resident
     ctx->err = "rt_sym_eig_values: not enough compute units for the cooperative tridiagonalisation";
     return RT_ERR_UNSUPPORTED;
@@ -674,7 +732,8 @@ extern "C" int rt_sym_eig_values_part(rt_ctx* ctx, const double* G, int64_t n, i
   // n <= 512: launch 16 x 32 blocks, of which the first 32 that find themselves on XCD eig_xcd work, so the 32
   // workers can hand off through one L2 (the kernel checks HW_REG_XCC_ID and falls back to the general form).
   // ROMTIME_EIG_FLAGS=1 disables it.
-  tp.spread = (!large && ctx->eig_one_xcd && !(eig_flags & 1) && ctx->num_cus / 8 >= tw) ? 1 : 0;  // a CU per worker
+  tp.spread = (!large && !local && ctx->eig_one_xcd && !(eig_flags & 1) && ctx->num_cus / 8 >= tw) ? 1 : 0;  // a CU per worker
+  tp.local = local ? 1 : 0;
   tp.xcd = ctx->eig_xcd & 7;
   tp.V = reinterpret_cast<double*>(b8 + oV); tp.P = reinterpret_cast<double*>(b8 + oP);
   tp.tau = reinterpret_cast<double*>(b8 + oT); tp.d = reinterpret_cast<double*>(b8 + oD);
@@ -684,7 +743,7 @@ extern "C" int rt_sym_eig_values_part(rt_ctx* ctx, const double* G, int64_t n, i
   hipLaunchKernelGGL(symeig_init_kernel, dim3(1), dim3(256), 0, st, tp.flags, tp.tau, (int)n);
 
   const int RB = (int)((n + tw - 1) / tw);
-  const size_t lds = sizeof(double) * ((size_t)RB * n + 4 * n + 16);  // A slab | v (x2) | w | row
+  const size_t lds = sizeof(double) * ((size_t)RB * (local ? n + 2 : n) + 5 * n + 16);  // A slab | v (x2) | w | row | p (local form)
   // n <= 256 has instantiations of its own (round 3): wave 0's register work per column - reflector, w, the updated row:
   // NM / 64 elements per lane - and the eigenvector kernel's back-transformation halve against the 512 ones
   static const bool small_nm = !(eig_flags & 2);
