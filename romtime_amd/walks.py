@@ -111,8 +111,9 @@ def upload_columns(vectors, zero_first_row=False):
     buffer - ``np.array(list)`` of a 205 MB set spends 21 ms mostly on the page faults of its fresh allocation, the
     stack into resident pinned memory 9 ms - and go over PCIe asynchronously (3.6 ms) while the caller assembles the
     next set (tools/probes/upload_probe.py).  ``zero_first_row``: the MDEIM convention (deim.py:388-389)."""
-    if not torch.cuda.is_available():
-        # host stand-ins for the operators (tests/cpu_stub.py); the real ops.to_device raises without a GPU
+    if getattr(ops.to_device, "__module__", ops.__name__) != ops.__name__ or not torch.cuda.is_available():
+        # the operators have been replaced by host stand-ins (tests/cpu_stub.py: the host-logic tests), or there is no
+        # GPU, in which case the real ops.to_device raises
         import numpy as np
 
         snapshots = np.array(vectors).T
