@@ -554,6 +554,10 @@ class PodWorkers:
                 # foreign call, during which the interpreter lock is released - the worker threads then really run side
                 # by side (with pod.pod_device the Python between a deep POD's kernels serialised them: 1.3x for eight)
                 Q, s, energy, levels = ops.pod_orth(X, num=kwargs["num"], tol=kwargs["tol"], normalize=kwargs["normalize"])
+                if 2 * Q.shape[1] < Q.stride(0):
+                    # with `tol` / default truncation the composite was given room for every column; the kept ones are a
+                    # view of that buffer, and a walk holds one result per set until the level is done: compact copy
+                    Q = Q.contiguous()
                 out = dict(Q=Q, s=s, energy=energy, VT=None, r=int(Q.shape[1]), passes=1 if levels <= 1 else "deflate",
                            levels=levels, colnorm=None)
             else:
