@@ -398,6 +398,10 @@ int rt_gemm_nn_axpby(rt_ctx* ctx, const double* X, int64_t ldx, int x_layout, co
     const int rc = rt_tallskinny(ctx, X, ldx, T, ldt, N, n, k, Y, ldy);  // tall X, few columns out: streaming kernel
     if (rc != RT_ERR_UNSUPPORTED) return rc;
   }
+  if (x_layout == RT_ROW_MAJOR && y_layout == RT_ROW_MAJOR && alpha == 1.0 && beta == 0.0 && N <= 64 && k >= 256 && n <= 2048) {
+    const int rc = rt_expansion_gemm(ctx, X, ldx, T, ldt, Y, ldy, N, n, k);  // few rows, short contraction, wide output
+    if (rc != RT_ERR_UNSUPPORTED) return rc;
+  }
   // contraction over the n columns of X: A(c, i) = X[i][c]
   const int64_t a_ks = (x_layout == RT_ROW_MAJOR) ? 1 : ldx, a_ms = (x_layout == RT_ROW_MAJOR) ? ldx : 1;
   const int64_t c_rs = (y_layout == RT_ROW_MAJOR) ? ldy : 1, c_cs = (y_layout == RT_ROW_MAJOR) ? 1 : ldy;

@@ -93,6 +93,9 @@ int rt_scratch2(rt_ctx* ctx, size_t bytes, void** out);
 // `symmetric`: A == B, M == Nn; only tiles on/above the diagonal are computed, then mirrored.
 // `allow_split`: contraction may be split over workgroups (deterministic slab reduction).
 // `alpha`, `beta`: C = alpha * (product) + beta * C (beta == 0: C is not read).
+// C (R x N) = G (R x K) Z (K x N), all row-major, R <= 64, short contraction (sweep.hip); RT_ERR_UNSUPPORTED otherwise
+int rt_expansion_gemm(rt_ctx* ctx, const double* G, long ldg, const double* Z, long ldz, double* Cm, long ldc, long R, long K,
+                      long N);
 int rt_gemm_strided(rt_ctx* ctx, const double* A, int64_t a_ks, int64_t a_ms, const double* B, int64_t b_ks,
                     int64_t b_ns, int64_t K, int64_t M, int64_t Nn, double* C, int64_t c_rs, int64_t c_cs,
                     bool symmetric, bool allow_split, double alpha = 1.0, double beta = 0.0);

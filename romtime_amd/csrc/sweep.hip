@@ -9,8 +9,131 @@
 //   u_h[b] = V u^{n+1}[b],   u* = 2 u_h - u_h^{n-1}                          next step's trilinear state
 // The operators are affine in precomputed value vectors on one CSR pattern (the form MDEIM itself
 // produces, and what a closed-form 1-D assembly yields); the state-dependent term is diag(u*) T.
+#include <cstdlib>
+
 #include "common.h"
 #include "sweep_advance.h"
+
+typedef double xd2 __attribute__((ext_vector_type(2)));
+typedef double xd4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// The expansion of the hyper-reduced step,  C (R x N) = G (R x K) Z (K x N)  with R <= 64 rows (K_N and M_N of all
+// parameter points), a SHORT contraction (K = the interpolation coefficients of all operators, a few hundred) and a
+// long N (r^2).  The generic GEMM walks the contraction in 16-deep stages with one stage of look-ahead: 18 stages of
+// ~0.9 us each, every one a global-memory round trip that 8 MFMAs per wave cannot hide - 16 us per step.  Here a
+// workgroup owns a 64 x 32 tile and takes the contraction in phases of EX_KP = 144: ALL loads of a phase (G's 64 rows,
+// the phase's 144 rows of Z's 32 columns) are issued at once, so a phase pays the memory latency once; two phases for
+// K = 280.  Operands through LDS in the two conflict-free images of the other kernels; each wave 16 rows x 32 columns.
+constexpr int EX_KP = 144, EX_SA = EX_KP + 2, EX_SB = 34, EX_THREADS = 256;
+constexpr int EX_LA = 64 * EX_KP / 2 / EX_THREADS;   // d2 loads of G per thread and phase (18)
+constexpr int EX_LB = EX_KP * 32 / 2 / EX_THREADS;   // d2 loads of Z per thread and phase (9)
+
+template <int MODE>   // 0; timing ablations (ROMTIME_SWEEP_FLAGS, results wrong): 6 = no global loads, 8 = one k-step, 14 = both
+__global__ __launch_bounds__(EX_THREADS) void expansion_kernel(const double* __restrict__ G, long ldg,
+                                                                const double* __restrict__ Z, long ldz,
+                                                                double* __restrict__ Cm, long ldc, int R, int K, long N) {
+  constexpr int mode = MODE;
+  extern __shared__ __attribute__((aligned(16))) double ex_sm[];
+  double* sA = ex_sm;                    // [64][EX_SA]: G rows, contraction contiguous
+  double* sB = ex_sm + 64 * EX_SA;       // [EX_KP][EX_SB]: Z rows of this tile's 32 columns
+  const int tid = threadIdx.x, lane = tid & 63, l15 = lane & 15, l4 = lane >> 4;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const long n0 = (long)blockIdx.x * 32;
+  // four independent accumulator chains per wave (two column tiles x the parity of the k-step): with one wave per SIMD
+  // nothing else hides the latency of an MFMA that waits for the previous one into the same accumulator
+  xd4 acc[2][2] = {{xd4{0, 0, 0, 0}, xd4{0, 0, 0, 0}}, {xd4{0, 0, 0, 0}, xd4{0, 0, 0, 0}}};
+  xd2 ra[EX_LA], rb[EX_LB];
+  // Branch-free loads: every load goes to a clamped, aligned address and is zeroed afterwards where it was out of range
+  // (even K, N and leading dimensions: the host checks) - a predicate per load makes the compiler wait for each load
+  // where it is issued.
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int i = 0; i < EX_LA; ++i) {
+      const int q = tid + EX_THREADS * i, row = q / (EX_KP / 2), kk = 2 * (q % (EX_KP / 2));
+      const int k = k0 + kk;
+      const bool ok = row < R && k < K;
+      const long off = (long)(row < R ? row : R - 1) * ldg + (k < K ? k : K - 2);
+      const xd2 v = (mode & 2) ? xd2{1.0, 1.0} : *reinterpret_cast<const xd2*>(G + off);
+      ra[i] = ok ? v : xd2{0.0, 0.0};
+    }
+#pragma unroll
+    for (int i = 0; i < EX_LB; ++i) {
+      const int q = tid + EX_THREADS * i, kk = q / 16, j = 2 * (q % 16);
+      const int k = k0 + kk;
+      const bool ok = k < K && n0 + j < N;
+      const long off = (long)(k < K ? k : K - 1) * ldz + (n0 + j < N ? n0 + j : N - 2);
+      const xd2 v = (mode & 4) ? xd2{1.0, 1.0} : *reinterpret_cast<const xd2*>(Z + off);
+      rb[i] = ok ? v : xd2{0.0, 0.0};
+    }
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < EX_LA; ++i) {
+      const int q = tid + EX_THREADS * i, row = q / (EX_KP / 2), kk = 2 * (q % (EX_KP / 2));
+      *reinterpret_cast<xd2*>(&sA[row * EX_SA + kk]) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < EX_LB; ++i) {
+      const int q = tid + EX_THREADS * i, kk = q / 16, j = 2 * (q % 16);
+      *reinterpret_cast<xd2*>(&sB[kk * EX_SB + j]) = rb[i];
+    }
+  };
+  const double* fa = sA + (16 * wid + l15) * EX_SA + l4;   // A operand: row 16 w + l15, k = 4 k4 + l4
+  const double* fb = sB + l4 * EX_SB + l15;                 // B operand: k = 4 k4 + l4, column 16 j + l15
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += EX_KP) {
+    commit();
+    __syncthreads();
+    if (k0 + EX_KP < K) fetch(k0 + EX_KP);   // the next phase's loads fly while this one is multiplied
+#pragma unroll
+    for (int k4 = 0; k4 < ((mode & 8) ? 2 : EX_KP / 4); ++k4) {
+      const double a = fa[4 * k4];
+      const double b0 = fb[4 * k4 * EX_SB], b1 = fb[4 * k4 * EX_SB + 16];
+      acc[0][k4 & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b0, acc[0][k4 & 1], 0, 0, 0);
+      acc[1][k4 & 1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc[1][k4 & 1], 0, 0, 0);
+    }
+    __syncthreads();   // the operands have been consumed: the next phase may overwrite them
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int row = 16 * wid + l4 + 4 * c;
+      const long col = n0 + 16 * j + l15;
+      if (row < R && col < N) Cm[(long)row * ldc + col] = acc[j][0][c] + acc[j][1][c];
+    }
+}
+
+}  // namespace
+
+// C = G Z for R <= 64 rows; RT_ERR_UNSUPPORTED beyond (the caller takes the generic GEMM).
+int rt_expansion_gemm(rt_ctx* ctx, const double* G, long ldg, const double* Z, long ldz, double* Cm, long ldc, long R,
+                      long K, long N) {
+  static const int flags = [] { const char* e = getenv("ROMTIME_SWEEP_FLAGS"); return e ? atoi(e) : 0; }();
+  const bool off = flags & 1;
+  if (off || R > 64 || R < 1 || K < 2 || N < 2 || ((K | N | ldg | ldz) & 1) ||
+      ((reinterpret_cast<size_t>(G) | reinterpret_cast<size_t>(Z)) & 15))
+    return RT_ERR_UNSUPPORTED;
+  const size_t lds = sizeof(double) * (64 * EX_SA + EX_KP * EX_SB);
+  const dim3 grid((unsigned)((N + 31) / 32));
+#define EX_LAUNCH(M_)                                                                                              \
+  {                                                                                                                \
+    RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&expansion_kernel<M_>), (int)lds));                      \
+    hipLaunchKernelGGL(expansion_kernel<M_>, grid, dim3(EX_THREADS), lds, ctx->stream, G, ldg, Z, ldz, Cm, ldc, (int)R, \
+                       (int)K, N);                                                                                 \
+  }
+  switch (flags & 14) {
+    case 6: EX_LAUNCH(6) break;
+    case 8: EX_LAUNCH(8) break;
+    case 14: EX_LAUNCH(14) break;
+    default: EX_LAUNCH(0) break;
+  }
+#undef EX_LAUNCH
+  RT_HIP_CHECK(ctx, hipGetLastError());
+  return RT_OK;
+}
 
 namespace {
 
@@ -316,7 +439,8 @@ extern "C" int rt_hrom_bdf_sweep(rt_ctx* ctx, const rt_hsweep_desc* d, double* u
       ctx->stream = gs;
       st = gs;
       RT_HIP_CHECK(ctx, hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
-      rc = rt_gemm_strided(ctx, G, 1, M, d->Z, rr, 1, M, 2 * B, rr, KN, rr, 1, false, false);
+      rc = rt_expansion_gemm(ctx, G, M, d->Z, rr, KN, rr, 2 * B, M, rr);
+      if (rc == RT_ERR_UNSUPPORTED) rc = rt_gemm_strided(ctx, G, 1, M, d->Z, rr, 1, M, 2 * B, rr, KN, rr, 1, false, false);
       rt_newton_rhs rq{MN, un, unm1, c0, c1, d->dt, mf ? d->F_rhs : nullptr, d->Zf, (int)mf};
       rq.ctr = ctr;
       rq.ff_stride = B * mf;
@@ -348,7 +472,8 @@ extern "C" int rt_hrom_bdf_sweep(rt_ctx* ctx, const rt_hsweep_desc* d, double* u
       break;
     }
     // [K_N; M_N][b][ij] = sum_e G[b][e] Z[e][ij]  (2 B rows)
-    rc = rt_gemm_strided(ctx, G, 1, M, d->Z, rr, 1, M, 2 * B, rr, KN, rr, 1, false, false);
+    rc = rt_expansion_gemm(ctx, G, M, d->Z, rr, KN, rr, 2 * B, M, rr);
+    if (rc == RT_ERR_UNSUPPORTED) rc = rt_gemm_strided(ctx, G, 1, M, d->Z, rr, 1, M, 2 * B, rr, KN, rr, 1, false, false);
     if (rc != RT_OK) return rc;
     rt_newton_rhs rq{MN, un, unm1, c0, c1, d->dt, mf ? d->F_rhs + step * B * mf : nullptr, d->Zf, (int)mf};
     // two launches per step: the expansion GEMM and the solve, which forms the right-hand side, falls back to a
