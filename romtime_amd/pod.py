@@ -328,11 +328,6 @@ def pod_device(X: torch.Tensor, num=None, tol=None, normalize=True, passes=None,
     if X.dim() != 2:
         raise ValueError("snapshots must be a 2-D array")
     n = X.shape[1]
-    if (n > DEVICE_EIG_MAX_N and X.is_cuda and DEVICE_EIG and X.shape[0] >= n and passes in (None, "deflate") and not want_vt
-            and (group is None or _world(group) == 1)):
-        wide = _pod_wide(X, num, tol, normalize)
-        if wide is not None:
-            return wide          # otherwise: not low-rank enough for the blocked route - host LAPACK below
     ctx = _lib.Context.current() if X.is_cuda else None
     prof = bool(ctx is not None and _profiling(ctx))
     t0 = time.perf_counter()
@@ -424,47 +419,6 @@ def pod_device(X: torch.Tensor, num=None, tol=None, normalize=True, passes=None,
     if prof:
         out["gram_kernel_ms"] = _PENDING_TIMINGS["gram_kernel_ms"]
     return out
-
-
-def _pod_wide(X, num, tol, normalize):
-    """More snapshot columns than the device eigensolver takes (n > 1024: the mu level of a tree walk over many
-    parameters, rom.py:368-384 - 50 parameters x 40 time-level modes = 2000 columns).  Snapshot sets of that width are
-    numerically low-rank, and that is used: the columns are split into blocks of <= 1024, every block is reduced to its
-    numerical rank by its own POD, X_b = Q_b S_b V_b^T with every mode above n eps sigma_1 kept, and
-    Y = [Q_1 S_1 | Q_2 S_2 | ...] has the same left singular vectors and singular values as X (the right factor
-    blkdiag(V_b) is orthogonal) up to the n eps sigma_1 that was dropped - inside the accuracy the Gram route has anyway.
-    If Y has at most 1024 columns its POD (same truncation rule, on the device) is the answer; otherwise None (the caller
-    takes host LAPACK for the n x n eigenproblem, as before).  All n singular values are returned: the ones beyond Y's
-    width as exact zeros (they are below n eps sigma_1)."""
-    N, n = X.shape
-    eps = np.finfo(float).eps
-    nblk = -(-n // DEVICE_EIG_MAX_N)
-    edges = [round(i * n / nblk) for i in range(nblk + 1)]
-    parts, width = [], 0
-    for a, b in zip(edges[:-1], edges[1:]):
-        # every mode down to the block's numerical rank (deflated levels; nothing enqueued ahead of the spectrum)
-        out = pod_device(X[:, a:b], num=b - a, normalize=normalize, passes="deflate")
-        sb = out["s"]
-        keep = int(np.count_nonzero(sb[: out["r"]] > (b - a) * eps * sb[0])) if sb[0] > 0 else 0
-        width += keep
-        if width > DEVICE_EIG_MAX_N:
-            return None
-        if keep:
-            parts.append(out["Q"][:, :keep] * ops.to_device(sb[:keep], X.device)[None, :])
-    if not parts:
-        return None
-    Y = torch.cat(parts, dim=1)
-    m = Y.shape[1]
-    top = pod_device(Y, num=(min(int(num), m) if (num and not tol) else None), tol=tol, normalize=False)
-    s = np.concatenate([top["s"], np.zeros(n - m)])
-    energy = np.concatenate([top["energy"], np.full(n - m, top["energy"][-1] if m else 1.0)])
-    r = truncation_rank(s, energy, num=num, tol=tol)
-    Q = top["Q"]
-    if Q.shape[1] < r:     # `num` beyond the numerical rank: zero columns, as the regular routes leave them
-        Q = torch.cat([Q, Q.new_zeros((N, r - Q.shape[1]))], dim=1)
-    elif Q.shape[1] > r:
-        Q = Q[:, :r].contiguous()
-    return dict(Q=Q, s=s, energy=energy, VT=None, r=r, passes="wide", colnorm=None, blocks=nblk, reduced_width=m)
 
 
 MAX_LEVELS = 12

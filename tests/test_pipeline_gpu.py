@@ -297,38 +297,3 @@ def test_fork_after_worker_threads_is_safe():
     assert d["ok"] == 1
     m.shutdown()
     workers.close()
-
-
-def test_wide_snapshot_sets_blocked_pod():
-    """n > 1024 columns (the mu level of a tree walk over many parameters): the device eigensolver takes n <= 1024, so
-    the columns are reduced block-wise to their numerical rank first (pod._pod_wide) - exact up to n eps sigma_1 for the
-    low-rank sets such stacks are; a set that is NOT low-rank falls back to host LAPACK as before.  Against dgesvd."""
-    from romtime_amd import ops, pod
-
-    rng = np.random.RandomState(31)
-    N, n, rank = 20_000, 1500, 70
-    U, _ = np.linalg.qr(rng.standard_normal((N, rank)))
-    V, _ = np.linalg.qr(rng.standard_normal((n, rank)))
-    X = (U * 10.0 ** (-10.0 * np.arange(rank) / (rank - 1))) @ V.T          # 10 decades, rank 70
-    Xd = ops.to_device(X)
-    for kw in (dict(num=25, normalize=False), dict(tol=1.0 - 1e-10, normalize=True), dict(normalize=False)):
-        out = pod.pod_device(Xd, **kw)
-        assert out["passes"] == "wide" and out["reduced_width"] <= 2 * rank + 4, (out["passes"], out.get("reduced_width"))
-        Qo, so, eo = oracle.orth(X, **kw)
-        assert out["r"] == Qo.shape[1] and out["s"].shape == so.shape == (n,)
-        bar = 2e-13 * so[0] + 8 * EPS * so[0] ** 2 / np.maximum(so, n * EPS * so[0])
-        assert np.all(np.abs(out["s"] - so) <= bar)
-        np.testing.assert_allclose(out["energy"], eo, rtol=1e-10)
-        Q = out["Q"].cpu().numpy()
-        assert np.abs(Q.T @ Q - np.eye(out["r"])).max() < 1e-9
-        k = min(out["r"], 20)                                              # well-separated leading modes: same subspace
-        assert np.linalg.norm(Q[:, :k] - Qo[:, :k] @ (Qo[:, :k].T @ Q[:, :k]), 2) < 1e-7
-    # through the drop-in: ndarray in, ndarrays out
-    Q, s, e = pod.orth(X, num=10, normalize=False)
-    assert Q.shape == (N, 10) and s.shape == (n,)
-    # not low-rank: the blocked route declines and the host eigenproblem takes over (same answers as before)
-    Xf = rng.standard_normal((3000, 1100))
-    out = pod.pod_device(ops.to_device(Xf), num=5, normalize=False)
-    assert out["passes"] != "wide"
-    so = np.linalg.svd(Xf, compute_uv=False)
-    np.testing.assert_allclose(out["s"][:5], so[:5], rtol=1e-10)
