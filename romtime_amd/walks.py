@@ -32,7 +32,14 @@ def _runner(device, kind):
         cache = _tls.runners = {}
     key = (device.index, kind)
     if key not in cache:
-        cache[key] = PodLanes(device=device.index) if kind == "lanes" else PodWorkers(device=device.index)
+        if kind == "lanes":
+            cache[key] = PodLanes(device=device.index)
+        elif kind == "pipeline":
+            from .pipeline import PodPipeline
+
+            cache[key] = PodPipeline(device=device.index)
+        else:
+            cache[key] = PodWorkers(device=device.index)
     return cache[key]
 
 
@@ -66,7 +73,16 @@ def pod_sequence(snapshot_sets, num=None, tol=None, normalize=True, cap=64):
             yield pod.pod_device(X, num=num, tol=tol, normalize=normalize)
         return
     kind = MODE if MODE != "auto" else "workers"
-    if kind == "lanes":
+    if MODE == "auto" and num and not tol:
+        from .pipeline import SMALL_SET
+
+        if first.numel() >= SMALL_SET:
+            # LARGE sets with the number of modes known beforehand: the CU-partitioned pipeline (eigensolve of one set
+            # beside the Gram of the next: 5.8 instead of 8.2 ms per 1e6 x 512 set) - what bench.py's headline measures
+            kind = "pipeline"
+    if kind == "pipeline":
+        yield from _runner(first.device, "pipeline").run(chain(), num=num, normalize=normalize)
+    elif kind == "lanes":
         yield from _runner(first.device, "lanes").run(chain(), num=num, tol=tol, normalize=normalize, cap=cap)
     else:
         yield from _runner(first.device, "workers").run(chain(), num=num, tol=tol, normalize=normalize)

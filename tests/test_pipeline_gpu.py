@@ -297,3 +297,22 @@ def test_fork_after_worker_threads_is_safe():
     assert d["ok"] == 1
     m.shutdown()
     workers.close()
+
+
+def test_walk_sequences_of_large_sets_take_the_pipeline():
+    """walks.pod_sequence routes LARGE snapshot sets with `num` truncation through PodPipeline (the form bench.py
+    measures) and everything else through the worker threads; same results either way."""
+    from romtime_amd import ops, pod, walks
+
+    rng = np.random.RandomState(41)
+    big = [ops.to_device(_matrix(rng, 400_000, 384, 2.0)) for _ in range(3)]          # 1.5e8 entries each
+    outs = list(walks.pod_sequence(big, num=12, normalize=True))
+    assert any(k[1] == "pipeline" for k in walks._tls.runners)
+    for Xd, out in zip(big, outs):
+        single = pod.pod_device(Xd, num=12, normalize=True)
+        np.testing.assert_allclose(out["s"][:12], single["s"][:12], rtol=1e-11)
+        Q, Qs = out["Q"].cpu().numpy(), single["Q"].cpu().numpy()
+        _same_columns(Q, Qs, 1e-10)
+    small = [ops.to_device(_matrix(rng, 5000, 64, 2.0)) for _ in range(3)]
+    outs = list(walks.pod_sequence(small, num=5, normalize=True))
+    assert [o["r"] for o in outs] == [5, 5, 5]
