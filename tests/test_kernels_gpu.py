@@ -428,6 +428,24 @@ def test_dense_solve_multi_matches_lapack(ops, m, nrhs):
         assert int(info.item()) != 0
 
 
+@pytest.mark.parametrize("R,K,N", [(64, 280, 6400), (64, 144, 320), (7, 2, 256), (33, 290, 1000), (64, 1000, 258),
+                                     (64, 281, 6400), (16, 280, 6401)])
+def test_few_rows_short_contraction_product(ops, R, K, N):
+    """ops.gemm_nn routes few-row (<= 64) / wide-output (>= 256) products to expansion_kernel (sweep.hip: the
+    hyper-reduced step's [K_N; M_N] = G Z); odd K or N fall back to the generic GEMM.  Both against the host product."""
+    rng = np.random.RandomState(R + K)
+    G, Z = rng.standard_normal((R, K)), rng.standard_normal((K, N))
+    C = ops.gemm_nn(ops.to_device(G), ops.to_device(Z)).cpu().numpy()
+    ref = G @ Z
+    assert np.abs(C - ref).max() <= 4 * EPS * K * np.abs(G).max() * np.abs(Z).max() * 4
+    # a strided output / operand view takes the same route
+    Gd = ops.to_device(np.c_[G, rng.standard_normal((R, 6))])[:, :K]
+    out = torch.zeros((R, N + 2), dtype=torch.float64, device="cuda")
+    ops.gemm_nn(Gd, ops.to_device(Z), out=out[:, :N])
+    assert np.abs(out[:, :N].cpu().numpy() - ref).max() <= 4 * EPS * K * np.abs(G).max() * np.abs(Z).max() * 4
+    assert float(out[:, N:].abs().max()) == 0.0
+
+
 def test_hyper_reduced_sweep_synthetic_and_singular_system(ops):
     """rt_hrom_bdf_sweep on random interpolation terms against oracle.hrom_solve, BDF1 and BDF2, r not a multiple of
     16; one parameter point gets an identically zero K_N: its inverse tracking fails, the device-side LU fallback
