@@ -9,6 +9,7 @@ from __future__ import annotations
 import ctypes as C
 import os
 import threading
+import weakref
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libromtime_hip.so")
@@ -118,6 +119,8 @@ class Context:
     """One rt_ctx per (thread, device); the stream follows torch's current stream."""
 
     _tls = threading.local()
+    _live = weakref.WeakSet()      # every ctx not yet destroyed (pipeline.shutdown unbinds them from streams it destroys)
+    _live_lock = threading.Lock()
 
     def __init__(self, device: int):
         import torch
@@ -133,6 +136,17 @@ class Context:
         self.handle = h
         self.options = {}
         self._pid = os.getpid()
+        with Context._live_lock:
+            Context._live.add(self)
+
+    @classmethod
+    def unbind_streams(cls):
+        """Point every live ctx at the null stream (before streams they may still be bound to are destroyed)."""
+        with cls._live_lock:
+            live = list(cls._live)
+        for ctx in live:
+            if ctx.handle and ctx._pid == os.getpid():
+                ctx.lib.rt_ctx_set_stream(ctx.handle, None)
 
     def __del__(self):
         # Not in a forked child: after fork() the interpreter drops the thread states of every thread but the forking

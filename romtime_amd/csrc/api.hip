@@ -190,7 +190,9 @@ int rt_ctx_create(rt_ctx** out, int device) {
 void rt_ctx_destroy(rt_ctx* ctx) {
   if (!ctx) return;
   (void)hipSetDevice(ctx->device);
-  (void)hipStreamSynchronize(ctx->stream);
+  // the whole device, not ctx->stream: the stream last bound to this ctx may be gone already (a CU-masked stream
+  // destroyed by the pipeline's shutdown before the interpreter drops the ctx), and hipFree below waits for the device anyway
+  (void)hipDeviceSynchronize();
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->scratch2) (void)hipFree(ctx->scratch2);
   if (ctx->dev_counters) (void)hipFree(ctx->dev_counters);
@@ -379,6 +381,10 @@ int rt_gemm_tn(rt_ctx* ctx, const double* A, int64_t lda, int a_layout, const do
   const int64_t a_ks = (a_layout == RT_ROW_MAJOR) ? lda : 1, a_ms = (a_layout == RT_ROW_MAJOR) ? 1 : lda;
   const int64_t b_ks = (b_layout == RT_ROW_MAJOR) ? ldb : 1, b_ns = (b_layout == RT_ROW_MAJOR) ? 1 : ldb;
   const bool sym = (A == B) && (m == n) && (lda == ldb) && (a_layout == b_layout);
+  if (!sym && a_layout == RT_ROW_MAJOR && b_layout == RT_ROW_MAJOR) {
+    const int rc = rt_skinny_tn(ctx, A, lda, B, ldb, N, m, n, C, ldc);  // few modes against a tall copy: streaming kernel
+    if (rc != RT_ERR_UNSUPPORTED) return rc;
+  }
   return rt_gemm_strided(ctx, A, a_ks, a_ms, B, b_ks, b_ns, N, m, n, C, ldc, 1, sym, true);
 }
 

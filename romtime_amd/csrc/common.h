@@ -107,6 +107,10 @@ int rt_gram128(rt_ctx* ctx, const double* X, int64_t ks, int64_t ms, int64_t K, 
 int rt_tallskinny(rt_ctx* ctx, const double* X, int64_t ldx, const double* T, int64_t ldt, int64_t N, int64_t n,
                   int64_t k, double* Y, int64_t ldy);
 
+// C = A^T B for few columns of A (rank_update.hip); RT_ERR_UNSUPPORTED outside its range.
+int rt_skinny_tn(rt_ctx* ctx, const double* A, int64_t lda, const double* B, int64_t ldb, int64_t N, int64_t m, int64_t n,
+                 double* Cm, int64_t ldc);
+
 // Newton-Schulz inverse tracking solve for the online sweep (solve.hip); RT_ERR_UNSUPPORTED for r > 80.
 struct rt_newton_rhs {  // b = M_N (c0 u^n + c1 u^{n-1}) + dt Zf^T F_rhs, per system; MN == nullptr: rhs is given
   const double* MN;    // B x r x r

@@ -67,6 +67,7 @@ def shutdown():
         gc.collect()
         torch.cuda.empty_cache()
         lib = _lib.load()
+        _lib.Context.unbind_streams()         # no ctx keeps the handle of a stream that is about to go
         for st in list(_STREAMS.values()):
             lib.rt_stream_destroy(_p(st.cuda_stream))
     finally:

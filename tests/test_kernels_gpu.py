@@ -56,6 +56,27 @@ def test_gemm_tn(ops, N, m, n, oa, ob):
     assert _rel(C, A.T @ B) < 5e-14
 
 
+@pytest.mark.parametrize("N,m,n,pad", [(70001, 1, 77, 0), (30000, 7, 201, 3), (20000, 16, 512, 0), (16385, 13, 600, 1),
+                                       (40000, 17, 130, 0), (300001, 8, 200, 0)])
+def test_gemm_tn_few_modes_streaming_kernel(ops, N, m, n, pad):
+    """Row-major A (N x m, a slice of a wider basis) against a tall row-major B with m <= 16 takes the streaming kernel
+    of the deflation sweep (rank_update.hip: skinny_tn): ragged row ranges, odd widths and leading dimensions (scalar
+    loads), more than one column strip (n > 512); m = 17 falls back to the generic GEMM.  Repeatable bit for bit."""
+    from romtime_amd._lib import Context
+
+    rng = np.random.RandomState(N + m + n)
+    Qh = rng.standard_normal((N, m + 5))
+    Bh = rng.standard_normal((N, n + pad))
+    A = ops.to_device(Qh)[:, 2:2 + m]
+    B = ops.to_device(Bh)[:, :n]
+    C = ops.gemm_tn(A, B)
+    tile = Context.current().launch_info()["tile"]
+    assert (tile[0] == m) == (m <= 16), tile
+    ref = Qh[:, 2:2 + m].T @ Bh[:, :n]
+    assert _rel(C.cpu().numpy(), ref) < 5e-14
+    assert torch.equal(C, ops.gemm_tn(A, B))
+
+
 @pytest.mark.parametrize("N,n,k", [(100, 8, 3), (5000, 64, 10), (4097, 256, 40), (3000, 33, 1), (2500, 512, 80), (999, 130, 130)])
 @pytest.mark.parametrize("order", ["C", "F"])
 def test_gemm_nn(ops, N, n, k, order):
