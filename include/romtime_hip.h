@@ -63,7 +63,11 @@ int rt_ctx_set_profile(rt_ctx* ctx, int on);
 int rt_ctx_set_option(rt_ctx* ctx, const char* name, int value);
 /* "cu_limit" (default 0 = the device's CU count; a multiple of 8): the number of CUs this ctx sizes its persistent grids
  * for - set it on a ctx whose stream is CU-masked (below) so that, e.g., the snapshot Gram kernel launches exactly the
- * workgroups its share of the chip holds. */
+ * workgroups its share of the chip holds.
+ * "gram_pace" (default 1): the workgroups of an XCD in the snapshot Gram kernel keep within two stages of each other
+ * (a progress word per XCD, bounded naps for leaders), so that the tiles sharing a panel read it from the L2 while it is
+ * still there: L2<-fabric reads of the off-diagonal launch 10.4 -> 4.13 GB on 1e6 x 512 at no cost in time on the whole
+ * chip; 0 switches it off (the POD pipeline does, for the Gram on its 224-CU stream: +2 % there). */
 
 /* CU-partitioned streams (throughput mode of the POD: the n x n eigensolve of one snapshot set runs beside the Gram
  * kernel of the next on disjoint CUs).  Creates a HIP stream whose kernels run only on CUs [first, first + count) of

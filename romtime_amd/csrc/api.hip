@@ -196,6 +196,7 @@ void rt_ctx_destroy(rt_ctx* ctx) {
   if (ctx->scratch) (void)hipFree(ctx->scratch);
   if (ctx->scratch2) (void)hipFree(ctx->scratch2);
   if (ctx->dev_counters) (void)hipFree(ctx->dev_counters);
+  if (ctx->gram_pace) (void)hipFree(ctx->gram_pace);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->gev0) (void)hipEventDestroy(ctx->gev0);
@@ -267,6 +268,10 @@ int rt_ctx_set_option(rt_ctx* ctx, const char* name, int value) {
       return RT_ERR_ARG;
     }
     ctx->eig_xcd = value;
+    return RT_OK;
+  }
+  if (key == "gram_pace") {
+    ctx->gram_pace_on = value != 0;
     return RT_OK;
   }
   if (key == "sweep_graph") {

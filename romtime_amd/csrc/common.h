@@ -40,6 +40,10 @@ struct rt_ctx {
   // Device-side event counters (hipMalloc'ed with the ctx, bumped by the kernels themselves because the host never
   // waits for them): rt_ctx_get_counter / rt_last_sweep_stats copy them back.
   long* dev_counters = nullptr;
+  // progress counters of the snapshot Gram kernels (gram_mfma.hip: per launch kind and XCD, {stages done, workgroups
+  // started}, 128 B apart); zeroed when allocated and again by every Gram's reduction kernel
+  unsigned long long* gram_pace = nullptr;
+  bool gram_pace_on = true;         // "gram_pace" option
 };
 
 // slots of rt_ctx::dev_counters

@@ -42,6 +42,9 @@ constexpr int BT = 128;
 constexpr int GT = 512;         // threads per workgroup: 8 waves as 2 (M) x 4 (N), 64 x 32 per wave
 constexpr int MAX_SLOTS = 64;   // workgroups per XCD
 constexpr int MAX_TILES = 36;   // upper-triangular 128-tiles: n <= 1024
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+constexpr unsigned long long PACE_ONE = 1ull << 40;   // one member of an XCD's pack (high 24 bits of its word)
+constexpr int PACE_DROP = 6;    // own stages behind the pack's mean beyond which a workgroup leaves the pack
 
 struct GramParams {
   const double* X;
@@ -50,6 +53,8 @@ struct GramParams {
   double* slab;       // [8][nslots][128*128]
   int nslots, tiles1, vec, flags;  // flags: 1 = s_setprio around the MFMA block, 2 = stagger odd wave slots
   long* counters;      // rt_ctx::dev_counters
+  unsigned long long* pace;  // this launch's progress counters ([8 XCDs][16]: {stages done, workgroups started}), or nullptr
+  int pace_every, pace_slack, pace_naps;   // check every so many stages; lead allowed (stages of its own); naps per check
   unsigned char slot_tm[MAX_SLOTS], slot_tn[MAX_SLOTS], slot_q[MAX_SLOTS], slot_S[MAX_SLOTS];
 };
 
@@ -96,6 +101,21 @@ __device__ __forceinline__ void gram_segment(const GramParams& p, double* smem, 
   const int lane = tid & 63, wid = tid >> 6;
   const int wm = wid >> 2, wn = wid & 3;
   const int l15 = lane & 15, l4 = lane >> 4;
+
+  // Pacing (a hint for L2 reuse, never a condition for progress).  The tiles of an XCD share a panel stage through the
+  // L2 only while they read it within the few microseconds it stays there, and nothing keeps workgroups together by
+  // itself: unpaced, the off-diagonal launch of 1e6 x 512 fetched 10.4 GB where perfect sharing needs 4.1; paced, 4.15 GB
+  // and 2 % less time (tools/probes/gram_pace_ab.sh).  One 64-bit word per XCD holds the PACK: the sum of its members'
+  // positions (stage index in the XCD's K range, low 40 bits) and their number (high 24 bits).  Every pace_every stages
+  // lane 0 of wave 0 adds the workgroup's advance with one returning atomic, issued behind the stage's panel loads:
+  //   - more than pace_slack of its own stages AHEAD of the pack's mean: nap ~0.45 us and look again, pace_naps times at most;
+  //   - more than PACE_DROP of its own stages BEHIND (started late: its CU was busy, or it is a second batch): it leaves
+  //     the pack - takes its position and itself out of the word - and runs unpaced, so the pack never waits for it.
+  // Workgroups that have not started are not in the word; finished ones stay in it and look like leaders.
+  unsigned long long* pace = p.pace ? p.pace + 16 * x : nullptr;
+  int pacer = (pace && __builtin_amdgcn_readfirstlane(wid) == 0 && nstages > 0) ? 1 : 0;
+  int pace_pos = 0, pace_cnt = 0;
+  if (pacer && lane == 0) __hip_atomic_fetch_add(pace, PACE_ONE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
   constexpr int NACC = DIAG ? 5 : 8;
   d4 acc[NACC];
@@ -182,6 +202,16 @@ __device__ __forceinline__ void gram_segment(const GramParams& p, double* smem, 
       constexpr int PAR = decltype(parity)::value;
       P::load_full_u(ra, gA, voff, rows_step);
       if constexpr (!DIAG) P::load_full_u(rb, gB, voff, rows_step);
+      // pacing: the advance goes in behind the panel loads and its answer (the word before the add) is back, like
+      // them, by the time the stage's vmcnt wait is over - nothing waits for the L2 round trip
+      const bool check = pacer && ++pace_cnt == p.pace_every;
+      unsigned long long before = 0;
+      if (check) {
+        pace_cnt = 0;
+        const int adv = S * p.pace_every;
+        if (lane == 0) before = __hip_atomic_fetch_add(pace, (unsigned long long)adv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        pace_pos += adv;
+      }
       if (p.flags & 1) __builtin_amdgcn_s_setprio(1);
       compute(PAR ? sA1 : sA0, PAR ? sB1 : sB0);
       if (p.flags & 1) __builtin_amdgcn_s_setprio(0);
@@ -189,6 +219,30 @@ __device__ __forceinline__ void gram_segment(const GramParams& p, double* smem, 
       gB += stage_step;
       P::store(ra, PAR ? sA0 : sA1, tid);
       if constexpr (!DIAG) P::store(rb, PAR ? sB0 : sB1, tid);
+      if (check) {
+        unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)before), hi = __builtin_amdgcn_readfirstlane((unsigned)(before >> 32));
+        unsigned long long word = (((unsigned long long)hi << 32) | lo) + (unsigned long long)(S * p.pace_every);
+#pragma unroll 1
+        for (int nap = 0;; ++nap) {
+          const long long total = (long long)(word & (PACE_ONE - 1)), members = (long long)(word >> 40);
+          const long long lead = (long long)pace_pos * members - total;          // (mine - mean) x members
+          if (lead < -(long long)PACE_DROP * S * members) {                     // a straggler: leave the pack
+            if (lane == 0)
+              __hip_atomic_fetch_add(pace, 0ull - (PACE_ONE + (unsigned long long)pace_pos), __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+            pacer = 0;
+            break;
+          }
+          if (lead <= (long long)p.pace_slack * S * members || nap >= p.pace_naps) break;
+          // The window is tight (a panel stage lives in the L2 for about two rounds), so the control is firm: nap
+          // ~0.45 us and look again, up to pace_naps times.  Gentler rules were measured and lose the sharing:
+          // two short naps per stage of excess lead without polling fetched 9 GB, a slack of 4 stages 8 GB.
+          __builtin_amdgcn_s_sleep(16);
+          u2 v;  // the word straight from the L2 (scalar load past the scalar cache)
+          asm volatile("s_load_dwordx2 %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(pace) : "memory");
+          word = ((unsigned long long)v.y << 32) | v.x;
+        }
+      }
       __syncthreads();
     };
     if (!(p.flags & 4))
@@ -288,6 +342,7 @@ struct GramReduceParams {
   long n;
   int nslots_off, nslots_diag, tiles1;
   unsigned char first[MAX_TILES], count[MAX_TILES];  // per upper-triangular tile, in its own launch's slots
+  unsigned long long* pace;  // rt_ctx::gram_pace (256 words), zeroed here for the next Gram; or nullptr
 };
 
 // Each thread on or above the diagonal sums its element over the 8 XCD slabs x sub-splits in a fixed order (rows
@@ -295,6 +350,7 @@ struct GramReduceParams {
 // and the slabs are read once (the mirrored half used to re-read them column-wise).
 __global__ void gram_reduce_kernel(const GramReduceParams p) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p.pace && idx < 256) p.pace[idx] = 0ull;
   if (idx >= p.n * p.n) return;
   const long i = idx / p.n, j = idx % p.n;
   if (i > j) return;
@@ -317,7 +373,8 @@ __global__ void gram_reduce_kernel(const GramReduceParams p) {
 
 template <bool KC, bool DIAG>
 int launch_gram(rt_ctx* ctx, const GramParams& p, int grid) {
-  constexpr size_t lds = sizeof(double) * (DIAG ? 2 : 4) * Panel<BT, KC, GT>::LDS;
+  size_t lds = sizeof(double) * (DIAG ? 2 : 4) * Panel<BT, KC, GT>::LDS;
+  if (p.flags & 128) lds = 100 * 1024;   // experiment: one workgroup per CU
   RT_TRY(rt_func_lds(ctx, reinterpret_cast<const void*>(&gram128_kernel<KC, DIAG>), (int)lds));
   hipLaunchKernelGGL((gram128_kernel<KC, DIAG>), dim3(grid), dim3(GT), lds, ctx->stream, p);
   RT_HIP_CHECK(ctx, hipGetLastError());
@@ -433,7 +490,8 @@ int rt_gram128(rt_ctx* ctx, const double* X, int64_t ks, int64_t ms, int64_t K, 
   const int tiles1 = (int)((n + BT - 1) / BT);
   const int ntiles = tiles1 * (tiles1 + 1) / 2;
   const int n_off = ntiles - tiles1;
-  const int slots_max = 2 * ctx->num_cus / 8;  // 2 workgroups per CU, per XCD
+  static const int occ1 = [] { const char* e = getenv("ROMTIME_GRAM_FLAGS"); return e ? (atoi(e) & 128) : 0; }();
+  const int slots_max = (occ1 ? 1 : 2) * ctx->num_cus / 8;  // 2 workgroups per CU, per XCD
   if (n < 97 || ntiles > MAX_TILES || n_off > slots_max || slots_max > MAX_SLOTS || K < 8L * 64 * KB)
     return RT_ERR_UNSUPPORTED;
   if (!(ks == 1 || ms == 1)) return RT_ERR_UNSUPPORTED;
@@ -450,6 +508,16 @@ int rt_gram128(rt_ctx* ctx, const double* X, int64_t ks, int64_t ms, int64_t K, 
   static const int env_flags = [] { const char* e = getenv("ROMTIME_GRAM_FLAGS"); return e ? atoi(e) : 1; }();
   p.flags = env_flags;
   p.counters = ctx->dev_counters;
+  p.pace = nullptr;
+  static const int pace_cfg = [] { const char* e = getenv("ROMTIME_GRAM_PACE"); return e ? atoi(e) : 228; }();  // every*100 + slack*10 + naps
+  p.pace_every = pace_cfg / 100 > 0 ? pace_cfg / 100 : 1; p.pace_slack = (pace_cfg / 10) % 10; p.pace_naps = pace_cfg % 10;
+  if (ctx->gram_pace_on && !(env_flags & 32)) {
+    if (!ctx->gram_pace) {
+      RT_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->gram_pace), sizeof(unsigned long long) * 256));
+      RT_HIP_CHECK(ctx, hipMemsetAsync(ctx->gram_pace, 0, sizeof(unsigned long long) * 256, ctx->stream));
+    }
+    p.pace = ctx->gram_pace;
+  }
 
   // ---- one launch (ROMTIME_GRAM_FLAGS & 16; long snapshot sets with off-diagonal tiles) --------------------------------
   // Measured (tools/probes/gram_merged_ab.sh, profiles/r03_gram_merged_ab.txt): perfectly balanced slots and one launch
@@ -460,6 +528,7 @@ int rt_gram128(rt_ctx* ctx, const double* X, int64_t ks, int64_t ms, int64_t K, 
   if ((env_flags & 16) && n_off >= 1) {
     GramSegs g;
     GramReduceParams rp;
+    if (!(env_flags & 64)) p.pace = nullptr;   // this plan's slots do not move through K at one rate: pacing them cost 70 %
     int nslabs = 0, s_off = 0;
     if (gram_plan(slots_max, tiles1, (int)(p.kx / KB), rho_pct / 100.0, g, rp.first, rp.count, &nslabs, &s_off)) {
       void* slab = nullptr;
@@ -467,7 +536,7 @@ int rt_gram128(rt_ctx* ctx, const double* X, int64_t ks, int64_t ms, int64_t K, 
       if (rc != RT_OK) return rc;
       p.slab = static_cast<double*>(slab); p.nslots = nslabs;
       rp.slab_off = rp.slab_diag = p.slab; rp.G = G; rp.n = n;
-      rp.nslots_off = rp.nslots_diag = nslabs; rp.tiles1 = tiles1;
+      rp.nslots_off = rp.nslots_diag = nslabs; rp.tiles1 = tiles1; rp.pace = p.pace;
       if (ctx->profile) {
         if (!ctx->ev0) {
           RT_HIP_CHECK(ctx, hipEventCreate(&ctx->ev0));
@@ -520,7 +589,7 @@ int rt_gram128(rt_ctx* ctx, const double* X, int64_t ks, int64_t ms, int64_t K, 
 
   GramReduceParams rp;
   rp.slab_off = slab_off; rp.slab_diag = slab_diag; rp.G = G; rp.n = n;
-  rp.nslots_off = nslots_off; rp.nslots_diag = nslots_diag; rp.tiles1 = tiles1;
+  rp.nslots_off = nslots_off; rp.nslots_diag = nslots_diag; rp.tiles1 = tiles1; rp.pace = ctx->gram_pace;
 
   if (ctx->profile) {
     if (!ctx->ev0) {
@@ -563,6 +632,7 @@ int rt_gram128(rt_ctx* ctx, const double* X, int64_t ks, int64_t ms, int64_t K, 
         }
       }
     p.slab = slab_diag; p.nslots = nslots_diag;
+    p.pace = (p.pace && (env_flags & 64)) ? ctx->gram_pace + 128 : nullptr;   // every panel has one reader here
     rc = kc ? launch_gram<true, true>(ctx, p, 8 * nslots_diag) : launch_gram<false, true>(ctx, p, 8 * nslots_diag);
     if (rc != RT_OK) return rc;
   }

@@ -126,6 +126,9 @@ class PodPipeline:
         self.ctxE.set_option("cu_limit", 8 * e)
         self.ctxE.set_option("eig_one_xcd", 0)       # the E CUs span all XCDs: write-through hand-off
         self.ctxG.set_option("cu_limit", 8 * g_count)
+        # the paced Gram (L2 sharing between the tiles of an XCD) costs nothing on the whole chip but 2 % on this stream's
+        # share of it (5.98 vs 5.87 ms per POD, tools/probes/pace_pipeline_ab.sh): off here unless asked for
+        self.ctxG.set_option("gram_pace", int(os.environ.get("ROMTIME_PIPELINE_GRAM_PACE", "0")))
         self.group = group
         # Row-sharded run: the small collectives of stream E (the broadcast of a set's eigen-results from the rank that
         # solved it) go through a process group of their own, so that they never queue behind the Gram all-reduce of the

@@ -34,6 +34,48 @@ def test_gram(ops, N, n, order):
     np.testing.assert_array_equal(G, G.T)  # exactly symmetric by construction
 
 
+@pytest.mark.parametrize("order", ["C", "F"])
+def test_gram_pacing_changes_nothing_but_the_timing(ops, order):
+    """The snapshot Gram kernel's workgroups pace themselves for L2 sharing (ctx option "gram_pace", default on): a
+    hint, never a condition - the same bits with it off, and with two Grams of different contexts and streams
+    competing for the CUs (late workgroups leave the pack instead of holding it back)."""
+    import threading
+
+    from romtime_amd._lib import Context
+
+    rng = np.random.RandomState(11)
+    Xh = rng.standard_normal((60_011, 384))
+    X = ops.to_device(np.asfortranarray(Xh) if order == "F" else Xh)
+    ctx = Context.current()
+    G_on = ops.gram(X)
+    assert ctx.launch_info()["tile"] == (128, 128)          # the gram128 route (the paced kernel)
+    ctx.set_option("gram_pace", 0)
+    try:
+        G_off = ops.gram(X)
+    finally:
+        ctx.set_option("gram_pace", 1)
+    assert torch.equal(G_on, G_off)
+    assert _rel(G_on.cpu().numpy(), Xh.T @ Xh) < 5e-14
+    out = {}
+
+    def worker(tag):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            st.wait_stream(torch.cuda.default_stream())
+            out[tag] = [ops.gram(X) for _ in range(6)]       # this thread's own ctx, its own progress words
+            st.synchronize()
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+        assert not t.is_alive()
+    for tag in range(3):
+        for G in out[tag]:
+            assert torch.equal(G, G_on)
+
+
 def test_mfma_layout_asymmetric(ops):
     """A = I-like selector against an asymmetric B catches swapped C/D row/col maps."""
     N, m, n = 64, 48, 80
