@@ -50,6 +50,7 @@ struct GramParams {
   const double* X;
   long ks, ms;        // X(k, i) at X[k*ks + i*ms]
   long K, n, kx;      // rows, columns, rows per XCD range (multiple of KB)
+  long last0;         // first column of the last tile row / column: (tiles1 - 1) * 128, or n - 128 (see rt_gram128)
   double* slab;       // [8][nslots][128*128]
   int nslots, tiles1, vec, flags;  // flags: 1 = s_setprio around the MFMA block, 2 = stagger odd wave slots
   long* counters;      // rt_ctx::dev_counters
@@ -89,7 +90,7 @@ __device__ __forceinline__ void gram_segment(const GramParams& p, double* smem, 
   // into the next (the off-diagonal loop has no VGPR to spare: values kept alive across segments were spilled in it)
   int tid = threadIdx.x;
   asm volatile("" : "+v"(tid));
-  const long m0 = (long)tm * BT, n0 = (long)tn * BT;
+  const long m0 = (tm == p.tiles1 - 1) ? p.last0 : (long)tm * BT, n0 = (tn == p.tiles1 - 1) ? p.last0 : (long)tn * BT;
   const long kend_x = ((long)x * p.kx + p.kx < p.K) ? (long)x * p.kx + p.kx : p.K;
   const int nst_x = (kend_x > (long)x * p.kx) ? (int)((kend_x - (long)x * p.kx + KB - 1) / KB) : 0;
   const int send = s1 < nst_x ? s1 : nst_x;
@@ -339,7 +340,7 @@ struct GramReduceParams {
   const double* slab_off;   // [8][nslots_off][128*128]
   const double* slab_diag;  // [8][nslots_diag][128*128]
   double* G;
-  long n;
+  long n, last0;
   int nslots_off, nslots_diag, tiles1;
   unsigned char first[MAX_TILES], count[MAX_TILES];  // per upper-triangular tile, in its own launch's slots
   unsigned long long* pace;  // rt_ctx::gram_pace (256 words), zeroed here for the next Gram; or nullptr
@@ -356,7 +357,7 @@ __global__ void gram_reduce_kernel(const GramReduceParams p) {
   if (i > j) return;
   const int tm = (int)(i / BT), tn = (int)(j / BT);
   const int t = tm * p.tiles1 - tm * (tm - 1) / 2 + (tn - tm);
-  const long off = (i % BT) * BT + (j % BT);
+  const long off = (i - (tm == p.tiles1 - 1 ? p.last0 : (long)tm * BT)) * BT + (j - (tn == p.tiles1 - 1 ? p.last0 : (long)tn * BT));
   const double* slab = (tm == tn) ? p.slab_diag : p.slab_off;
   const int nslots = (tm == tn) ? p.nslots_diag : p.nslots_off;
   const int cnt = p.count[t];
@@ -389,13 +390,38 @@ int launch_gram(rt_ctx* ctx, const GramParams& p, int grid) {
 //   a diagonal tile that needs more than s_d T* gets H off-diagonal slots as helpers for the last 1 - phi of the range,
 //   phi from  phi rho / s_d = 1 / S_off + (1 - phi) rho / H  (dedicated slots and helpers finish together).
 // Fills the segments, the slab index of every segment and the per-tile slab lists of the reduction.
+// Slots per off-diagonal (a) and per diagonal tile (b) of the uniform plan below; returns the slowest slot's time per
+// stage of the range, max(1/a, rho/b), or 0 when there is no such plan.
+double gram_uniform_ab(int P, int n_off, int n_d, double rho, int* a_out, int* b_out) {
+  double best = 1e30;
+  int best_slots = 0;
+  *a_out = *b_out = 0;
+  for (int a = 1; n_off * a + n_d <= P; ++a)
+    for (int b = 1; n_off * a + n_d * b <= P; ++b) {
+      const double T = (1.0 / a > rho / b) ? 1.0 / a : rho / b;
+      const int used = n_off * a + n_d * b;
+      if (T < best - 1e-12 || (T < best + 1e-12 && used < best_slots)) { best = T; *a_out = a; *b_out = b; best_slots = used; }
+    }
+  return *a_out ? best : 0.0;
+}
+
+// `uniform`: no helpers - every off-diagonal tile gets a slots and every diagonal tile b, (a, b) minimising the slowest
+// slot's time max(1/a, rho/b) within P slots (fewest slots among equals).  All slots then move through the K range at
+// about one rate (a vs b/rho stages per unit of time; pacing trims the rest), so ALL tiles of an XCD read a panel stage
+// while it is in the L2: one read of X per Gram, at the price of slots that idle part of the time.
 bool gram_plan(int P, int tiles1, int nst, double rho, GramSegs& g, unsigned char* first, unsigned char* count, int* nslabs,
-               int* s_off_out) {
+               int* s_off_out, bool uniform = false) {
   const int n_d = tiles1, n_off = tiles1 * (tiles1 - 1) / 2;
   if (n_off < 1 || P > MAX_SLOTS) return false;
   const double W = n_off + rho * n_d, Tstar = W / P;
   int S_off = (int)(1.0 / Tstar - 1e-9) + 1;
   while (S_off >= 1 && n_off * S_off + n_d > P) --S_off;
+  int uni_b = 0;
+  if (uniform) {
+    int best_a = 0;
+    if (gram_uniform_ab(P, n_off, n_d, rho, &best_a, &uni_b) <= 0.0) return false;
+    S_off = best_a;
+  }
   if (S_off < 1 || nst < 48 * S_off) return false;   // short sets: the two-launch form with its own caps
   const int rem = P - n_off * S_off;
   int s_d[8], H[8] = {0}, n1[8];
@@ -405,6 +431,7 @@ bool gram_plan(int P, int tiles1, int nst, double rho, GramSegs& g, unsigned cha
     s_d[i] = rem / n_d + (i < rem % n_d ? 1 : 0);
     need[i] = rho - s_d[i] * Tstar;
     if (need[i] < 1e-3 * rho || spare <= 1e-3 * Tstar) need[i] = 0.0;
+    if (uniform) { s_d[i] = uni_b; need[i] = 0.0; }
     total_need += need[i];
   }
   int helpers_left = n_off * S_off;
@@ -470,7 +497,7 @@ bool gram_plan(int P, int tiles1, int nst, double rho, GramSegs& g, unsigned cha
   if (slab > 255) return false;
   *nslabs = slab;
   *s_off_out = S_off;
-  return slot == P;
+  return uniform ? slot <= P : slot == P;
 }
 
 template <bool KC>
@@ -503,14 +530,26 @@ int rt_gram128(rt_ctx* ctx, const double* X, int64_t ks, int64_t ms, int64_t K, 
   p.tiles1 = tiles1;
   const long other = kc ? ms : ks;
   p.vec = ((((uintptr_t)X) & 15) == 0 && (other % 2 == 0)) ? 1 : 0;
+  // A last tile row / column that is not full (n no multiple of 128) would take the predicated loader for every stage:
+  // 7.0 ms at n = 500 against 4.4 at n = 512.  Instead the last panel is SHIFTED to end at column n (it overlaps its
+  // left neighbour; 16-byte alignment of its rows asks for an even n in row-major order): all panels are full, every tile
+  // takes the fast loader, the entries computed twice are taken from the tile that owns them by the reduction.
+  p.last0 = (long)(tiles1 - 1) * BT;
+  if (n % BT != 0 && n >= BT && p.vec && (kc || n % 2 == 0)) p.last0 = n - BT;
   // the scalar-base loader keeps a 32-bit per-thread byte offset of up to 8 rows: beyond that, the predicated loader
   if ((!kc && (long)ks * 8 * 8 >= (1L << 31)) || (kc && (long)ms * 64 * 8 >= (1L << 31))) p.vec = 0;
   static const int env_flags = [] { const char* e = getenv("ROMTIME_GRAM_FLAGS"); return e ? atoi(e) : 1; }();
   p.flags = env_flags;
   p.counters = ctx->dev_counters;
   p.pace = nullptr;
-  static const int pace_cfg = [] { const char* e = getenv("ROMTIME_GRAM_PACE"); return e ? atoi(e) : 228; }();  // every*100 + slack*10 + naps
-  p.pace_every = pace_cfg / 100 > 0 ? pace_cfg / 100 : 1; p.pace_slack = (pace_cfg / 10) % 10; p.pace_naps = pace_cfg % 10;
+  // pacing: every*100 + slack*10 + naps.  Two launches (equal workgroups, only jitter to correct): every 2 stages, 2
+  // stages of slack; one launch (diagonal slots are ~1/6 faster and must be held back all the time): 1 stage of slack
+  static const int pace_env = [] { const char* e = getenv("ROMTIME_GRAM_PACE"); return e ? atoi(e) : 0; }();
+  auto set_pace = [&](int cfg) {
+    if (pace_env) cfg = pace_env;
+    p.pace_every = cfg / 100 > 0 ? cfg / 100 : 1; p.pace_slack = (cfg / 10) % 10; p.pace_naps = cfg % 10;
+  };
+  set_pace(228);
   if (ctx->gram_pace_on && !(env_flags & 32)) {
     if (!ctx->gram_pace) {
       RT_HIP_CHECK(ctx, hipMalloc(reinterpret_cast<void**>(&ctx->gram_pace), sizeof(unsigned long long) * 256));
@@ -525,17 +564,32 @@ int rt_gram128(rt_ctx* ctx, const double* X, int64_t ks, int64_t ms, int64_t K, 
   // reads 12.9 vs 13.6 GB.  The kernel runs at the board's power limit: the slots the two-launch form leaves idle (4 of
   // 64 in the off-diagonal launch) are not lost time, the busy ones clock higher.  Kept as a switch, not the default.
   static const int rho_pct = [] { const char* e = getenv("ROMTIME_GRAM_RHO"); return e ? atoi(e) : 60; }();
-  if ((env_flags & 16) && n_off >= 1) {
+  // ---- which plan --------------------------------------------------------------------------------------------------------
+  // One launch with uniform slots reads X once (4.15 GB on 1e6 x 512 against 8.2 for two paced launches and 14.5 unpaced)
+  // but leaves slots idle part of the time; it is taken when pacing is on and the model says it costs at most 5 % more
+  // than two launches - where it then measured 1-6 % FASTER (n = 256, 384, 512, 1024: tools/probes/gram_shapes.py);
+  // n = 640 / 768 (model 1.15 / 1.07, measured 1.12 / 1.05) and the pipeline's 56 slots (1.08, measured 1.08) stay with
+  // two launches.  ROMTIME_GRAM_FLAGS & 256 forces it, & 512 forbids it.
+  bool uniform = (env_flags & 256) != 0;
+  if (!uniform && !(env_flags & (16 | 512)) && n_off >= 1 && p.pace) {
+    int a = 0, b = 0;
+    const double t_uni = gram_uniform_ab(slots_max, n_off, tiles1, rho_pct / 100.0, &a, &b);
+    const double t_two = 1.0 / (slots_max / n_off) + (rho_pct / 100.0) / (slots_max / tiles1);
+    uniform = t_uni > 0.0 && t_uni <= 1.05 * t_two;
+  }
+  if (((env_flags & 16) || uniform) && n_off >= 1) {
     GramSegs g;
     GramReduceParams rp;
-    if (!(env_flags & 64)) p.pace = nullptr;   // this plan's slots do not move through K at one rate: pacing them cost 70 %
+    if (uniform) set_pace(218);
+    // the helper plan's slots do not move through K at one rate: pacing them cost 70 %
+    if (!uniform && !(env_flags & 64)) p.pace = nullptr;
     int nslabs = 0, s_off = 0;
-    if (gram_plan(slots_max, tiles1, (int)(p.kx / KB), rho_pct / 100.0, g, rp.first, rp.count, &nslabs, &s_off)) {
+    if (gram_plan(slots_max, tiles1, (int)(p.kx / KB), rho_pct / 100.0, g, rp.first, rp.count, &nslabs, &s_off, uniform)) {
       void* slab = nullptr;
       int rc = rt_scratch(ctx, sizeof(double) * BT * BT * 8 * (size_t)nslabs, &slab);
       if (rc != RT_OK) return rc;
       p.slab = static_cast<double*>(slab); p.nslots = nslabs;
-      rp.slab_off = rp.slab_diag = p.slab; rp.G = G; rp.n = n;
+      rp.slab_off = rp.slab_diag = p.slab; rp.G = G; rp.n = n; rp.last0 = p.last0;
       rp.nslots_off = rp.nslots_diag = nslabs; rp.tiles1 = tiles1; rp.pace = p.pace;
       if (ctx->profile) {
         if (!ctx->ev0) {
@@ -565,7 +619,8 @@ int rt_gram128(rt_ctx* ctx, const double* X, int64_t ks, int64_t ms, int64_t K, 
     }
   }
 
-  // ---- two launches (the default) -------------------------------------------------------------------------------------
+  set_pace(228);
+  // ---- two launches -------------------------------------------------------------------------------------
   int S_off = n_off ? slots_max / n_off : 0;   // sub-splits per off-diagonal tile per XCD
   int S_diag = slots_max / tiles1;             // ... per diagonal tile
   // Shorter snapshot sets get fewer sub-splits, at least 48 stages each (below that the slab traffic and the two
@@ -588,7 +643,7 @@ int rt_gram128(rt_ctx* ctx, const double* X, int64_t ks, int64_t ms, int64_t K, 
   double* slab_diag = slab_off + (size_t)8 * nslots_off * BT * BT;
 
   GramReduceParams rp;
-  rp.slab_off = slab_off; rp.slab_diag = slab_diag; rp.G = G; rp.n = n;
+  rp.slab_off = slab_off; rp.slab_diag = slab_diag; rp.G = G; rp.n = n; rp.last0 = p.last0;
   rp.nslots_off = nslots_off; rp.nslots_diag = nslots_diag; rp.tiles1 = tiles1; rp.pace = ctx->gram_pace;
 
   if (ctx->profile) {

@@ -34,6 +34,25 @@ def test_gram(ops, N, n, order):
     np.testing.assert_array_equal(G, G.T)  # exactly symmetric by construction
 
 
+@pytest.mark.parametrize("N,n,order", [(300_000, 200, "C"), (200_000, 500, "C"), (150_000, 384, "F"), (120_000, 1000, "C"),
+                                       (260_000, 250, "F"), (200_000, 641, "C"), (131_077, 512, "C")])
+def test_gram_long_sets(ops, N, n, order):
+    """Long snapshot sets: the one-launch plan of the Gram kernel where its model takes it (n <= 512, n = 1000), two
+    launches elsewhere; a last tile column that is not full is a panel shifted to end at column n (even n) or the
+    predicated loader (odd n); ragged K tails.  Exactly symmetric, equal to numpy's X^T X."""
+    from romtime_amd._lib import Context
+
+    rng = np.random.RandomState(N % 1000 + n)
+    Xh = rng.standard_normal((N, n))
+    Xh[:, n // 2] *= 1e3                                     # a misplaced column would show
+    X = ops.to_device(np.asfortranarray(Xh) if order == "F" else Xh)
+    G = ops.gram(X)
+    assert Context.current().launch_info()["tile"] == (128, 128)
+    assert torch.equal(G, G.T)
+    assert _rel(G.cpu().numpy(), Xh.T @ Xh) < 5e-14
+    assert torch.equal(G, ops.gram(X))
+
+
 @pytest.mark.parametrize("order", ["C", "F"])
 def test_gram_pacing_changes_nothing_but_the_timing(ops, order):
     """The snapshot Gram kernel's workgroups pace themselves for L2 sharing (ctx option "gram_pace", default on): a

@@ -5,7 +5,7 @@ cd $R
 for i in 1 2 3; do
   for FC in ${1:-1:228 33:228}; do
     F=${FC%%:*}; C=${FC##*:}
-    ROMTIME_GRAM_PACE=$C ROMTIME_GRAM_FLAGS=$F timeout -k 10 120 python3 bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-secondary --no-latency > $O/run_${F}_${C}_$i.json 2>/dev/null || exit 1
+    ROMTIME_PIPELINE_GRAM_PACE=${PIPE_PACE:-0} ROMTIME_GRAM_PACE=$C ROMTIME_GRAM_FLAGS=$F timeout -k 10 120 python3 bench.py --steps 40 --warmup 8 --no-cpu-baseline --no-secondary --no-latency > $O/run_${F}_${C}_$i.json 2>/dev/null || exit 1
   done
 done
 python3 - <<PY
