@@ -148,6 +148,27 @@ class Context:
             if ctx.handle and ctx._pid == os.getpid():
                 ctx.lib.rt_ctx_set_stream(ctx.handle, None)
 
+    def destroy(self):
+        """Release the device resources of this ctx now (idempotent; a destroyed ctx must not be used again)."""
+        try:
+            if getattr(self, "handle", None) and getattr(self, "_pid", None) == os.getpid():
+                self.lib.rt_ctx_destroy(self.handle)
+        finally:
+            self.handle = None
+
+    @classmethod
+    def destroy_all(cls):
+        """Destroy every live ctx of the process (``romtime_amd.shutdown``): threads that still hold one - the calling
+        thread's cache included - get a fresh one on their next operator call."""
+        with cls._live_lock:
+            live = list(cls._live)
+            cls._live.clear()
+        for ctx in live:
+            ctx.destroy()
+        cache = getattr(cls._tls, "cache", None)
+        if cache:
+            cache.clear()
+
     def __del__(self):
         # Not in a forked child: after fork() the interpreter drops the thread states of every thread but the forking
         # one, and with them the thread-local contexts of worker threads (pipeline.PodWorkers) - their finalisers would
@@ -173,7 +194,7 @@ class Context:
         if cache is None:
             cache = cls._tls.cache = {}
         ctx = cache.get(dev)
-        if ctx is None:
+        if ctx is None or not ctx.handle:      # none yet, or destroyed by destroy_all() from another thread
             ctx = cache[dev] = cls(dev)
         ctx.lib.rt_ctx_set_stream(ctx.handle, _p(torch.cuda.current_stream().cuda_stream))
         return ctx

@@ -404,6 +404,10 @@ class PodLanes:
             self.streams.append(torch.cuda.Stream(self.device))
         self.recomputed = 0
 
+    def close(self):
+        """Wait for everything in flight on the lanes' streams."""
+        torch.cuda.synchronize(self.device)
+
     def _enqueue(self, item, lane):
         X, k, normalize = item["X"], item["k"], item["normalize"]
         n = X.shape[1]

@@ -43,6 +43,19 @@ def _runner(device, kind):
     return cache[key]
 
 
+def close_runners():
+    """Close the sequence runners this thread has cached (joins the worker threads); the next walk makes new ones."""
+    cache = getattr(_tls, "runners", None)
+    if not cache:
+        return
+    for runner in list(cache.values()):
+        try:
+            runner.close()
+        except Exception:
+            pass
+    cache.clear()
+
+
 # "workers": every set runs the whole POD in a thread of its own (any truncation rule, deep spectra included);
 # "lanes": whole chains enqueued ahead of the spectrum from one thread (`num` truncation of shallow spectra only: deep
 # sets are recomputed one after the other).  Measured, 16 device-resident sets of 1e5 x 256, 40 modes + the POD of their

@@ -14,6 +14,19 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionfinish(session, exitstatus):
+    """End of a GPU session: give everything back explicitly, in order, before the interpreter starts finalising."""
+    mod = sys.modules.get("romtime_amd")
+    if mod is not None:
+        try:
+            import torch
+
+            if torch.cuda.is_available():
+                mod.shutdown()
+        except Exception as exc:   # never turn a finished session into a failure
+            print(f"romtime_amd.shutdown() at session end: {exc!r}", file=sys.stderr)
+
+
 def load_golden(name):
     return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
 

@@ -316,3 +316,28 @@ def test_walk_sequences_of_large_sets_take_the_pipeline():
     small = [ops.to_device(_matrix(rng, 5000, 64, 2.0)) for _ in range(3)]
     outs = list(walks.pod_sequence(small, num=5, normalize=True))
     assert [o["r"] for o in outs] == [5, 5, 5]
+
+
+def test_package_shutdown_gives_everything_back_and_the_package_works_on():
+    """romtime_amd.shutdown(): runners closed (worker threads joined), masked streams and every context destroyed, in
+    that order; the next call makes new ones and computes the same bits."""
+    import threading
+
+    import romtime_amd
+    from romtime_amd import ops, pod, walks
+    from romtime_amd._lib import Context
+
+    rng = np.random.RandomState(77)
+    sets = [ops.to_device(_matrix(rng, 5000, 48, 2.0)) for _ in range(4)]
+    before = list(walks.pod_sequence(sets, tol=1.0 - 1e-9, normalize=True))
+    big = pod.pod_device(sets[0], num=5, normalize=True)
+    assert any(t.name.startswith("romtime-pod") for t in threading.enumerate())
+    romtime_amd.shutdown()
+    assert not any(t.name.startswith("romtime-pod") for t in threading.enumerate())
+    assert len(Context._live) == 0 and not walks._tls.runners
+    after = list(walks.pod_sequence(sets, tol=1.0 - 1e-9, normalize=True))
+    for a, b in zip(before, after):
+        assert a["r"] == b["r"] and torch.equal(a["Q"], b["Q"])
+        np.testing.assert_array_equal(a["s"], b["s"])
+    again = pod.pod_device(sets[0], num=5, normalize=True)
+    assert torch.equal(big["Q"], again["Q"])
