@@ -98,6 +98,7 @@ struct ProjParams {
   int N, k_per_split;
   int r, B, S;
   int flags;
+  int xcd_map;          // 1: workgroups of an XCD take a contiguous run of the range-major work list (see the kernel)
   const StageRec* rec;  // [stages]; handed to the kernel as an argument of its own (see project_fused_kernel)
   const int* any_unwindowed;
 };
@@ -183,7 +184,23 @@ __device__ __forceinline__ void project_wave(const ProjParams& p, const StageRec
   Entry* sEnt = reinterpret_cast<Entry*>(sB + PK * STRIDE);   // [EMAX + EPAD]
   const int tid = threadIdx.x, lane = tid & 63;
   const int l15 = lane & 15, l4 = lane >> 4;
-  const int b = blockIdx.x % p.B, s = blockIdx.x / p.B;
+  // Which (value vector b, DoF range s).  Workgroup i runs on XCD i % 8 (checked for the Gram kernel: counter
+  // gram_off_xcd), and each XCD has its own L2: with b = i % B the B readers of a range's rows of V were spread over all
+  // eight XCDs and V came in from the fabric up to eight times (764 MB per 32-vector launch against 192 algorithmic).
+  // Instead XCD x takes the x-th eighth of the work list ordered by (s, b): the readers of a range sit on one XCD - two
+  // at a boundary - next to each other in dispatch order, and share its rows through that XCD's L2.
+  int b, s;
+  if (p.xcd_map) {
+    const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int total = p.B * p.S, per = (total + 7) >> 3;
+    const int i = x * per + j;
+    if (j >= per || i >= total) return;   // padding of the grid (whole workgroup, before any barrier)
+    s = i / p.B;
+    b = i - s * p.B;
+  } else {
+    b = blockIdx.x % p.B;
+    s = blockIdx.x / p.B;
+  }
   const int r = p.r;
   const int kbeg = s * p.k_per_split;                         // multiple of PK
   const int kend = (kbeg + p.k_per_split < p.N) ? kbeg + p.k_per_split : p.N;
@@ -611,7 +628,9 @@ int rt_project_fused(rt_ctx* ctx, const int64_t* indptr, const int64_t* indices,
     }
     RT_HIP_CHECK(ctx, hipEventRecord(ctx->ev0, ctx->stream));
   }
-  const unsigned grid = (unsigned)(B * S);
+  static const int xcd_map = [] { const char* e = getenv("ROMTIME_PROJECT_MAP"); return e ? atoi(e) : 1; }();
+  p.xcd_map = xcd_map;
+  const unsigned grid = xcd_map ? (unsigned)(((B * S + 7) / 8) * 8) : (unsigned)(B * S);
   switch (tr) {
     case 1: rc = launch_fused<1>(ctx, p, grid, banded); break;
     case 2: rc = launch_fused<2>(ctx, p, grid, banded); break;
