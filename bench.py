@@ -377,7 +377,7 @@ def main():
             dist.init_process_group(backend=backend, rank=rank, world_size=world)
         group = dist.group.WORLD
 
-    from romtime_amd import pod
+    from romtime_amd import ops, pod
     from romtime_amd._lib import Context
 
     n_h, n, r = args.rows, args.cols, args.modes
@@ -397,6 +397,7 @@ def main():
 
     mode = args.mode if args.mode != "auto" else "pipeline"
     latency_ms = None
+    whole_chip_gram_ms = None
     pipe, why_not = None, None
     if mode == "pipeline":
         # The K steps are K independent PODs (as the per-parameter PODs of a tree walk are): PodPipeline keeps two of
@@ -443,6 +444,16 @@ def main():
                 pod.pod_device(X, num=r, normalize=True)
             torch.cuda.synchronize()
             latency_ms = 1e3 * (time.perf_counter() - t1) / 5
+            # the Gram kernel on the whole chip (what a single POD runs: one launch, paced - see DESIGN section 4), its
+            # own HIP event pair on the ctx stream
+            ctx.set_profile(True)
+            whole = []
+            for _ in range(5):
+                ops.gram(X)
+                torch.cuda.synchronize()
+                whole.append(ctx.last_gram_ms())
+            ctx.set_profile(False)
+            whole_chip_gram_ms = float(np.mean(whole))
         del outs
         pipe.close()
         counts = [pipe.ctxE.counter(c) + ctx.counter(c) for c in FALLBACK_COUNTERS[:3]] + [pipe.recomputed]
@@ -515,6 +526,15 @@ def main():
                              "(2.4 GHz x 32 flop/clk/SIMD); this part sustains 47-48 TF on FP64 MFMAs alone with the pipe "
                              "saturated (profiles/r03_mfma_sustained.txt) and 66.7 TF in this kernel on all-zero data: "
                              "the kernel runs at the board's power limit")
+        if whole_chip_gram_ms is not None and whole_chip_gram_ms == whole_chip_gram_ms:
+            wc_traffic = tj.get("whole_chip", {}).get("hbm_bytes_per_gram") if traffic is not None else None
+            wc = alg_flops / (whole_chip_gram_ms * 1e-3) / 1e12
+            roofline["whole_chip_launch"] = dict(
+                kernel="gram128_merged_kernel<KC> (the Gram of a POD on its own: all 256 CUs, one launch, workgroups of an "
+                       "XCD paced so that every panel is fetched once)",
+                kernel_ms=whole_chip_gram_ms, achieved=wc, frac=wc / FP64_MFMA_PEAK_TFLOPS, traffic=wc_traffic,
+                traffic_source=(f"static: profiles/gram_traffic.json ({tj['whole_chip'].get('source')})"
+                                if wc_traffic is not None else None))
         line = base_line(args, world, n_local, value, ms_per_step, out["passes"], mode, latency_ms)
         line["stage_ms"] = {k: round(v, 4) for k, v in stage_ms.items()}
         line["roofline"] = roofline

@@ -71,13 +71,25 @@ def main():
                 cs["mfma_util"] = cs["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / cyc
     with open(os.path.join(ROOT, "profiles", f"{a.tag}_pmc.json"), "w") as fp:
         json.dump(pmc, fp, indent=1, sort_keys=True)
-    gram = [cs["hbm_bytes_per_launch"] for k, cs in pmc.items() if k.startswith("gram128_kernel") and "hbm_bytes_per_launch" in cs]
+    gram = [cs["hbm_bytes_per_launch"] for k, cs in pmc.items() if k.startswith("gram128_") and "hbm_bytes_per_launch" in cs]
+    tfile = os.path.join(ROOT, "profiles", "gram_traffic.json")
     if gram and "_bench_" in a.tag:   # only the headline workload's passes describe the bench line's Gram
-        with open(os.path.join(ROOT, "profiles", "gram_traffic.json"), "w") as fp:
-            json.dump(dict(hbm_bytes_per_gram=sum(gram), source=f"profiles/{a.tag}_pmc.json",
-                           workload="pod_1000000x512 on 1 GPU (bench.py default)",
-                           method="2*FETCH_SIZE*1024 + WRITE_SIZE*1024, separate --pmc passes, summed over the "
-                                  "off-diagonal and diagonal launches"), fp, indent=1)
+        old = json.load(open(tfile)) if os.path.exists(tfile) else {}
+        rec = dict(hbm_bytes_per_gram=sum(gram), source=f"profiles/{a.tag}_pmc.json",
+                   workload="pod_1000000x512 on 1 GPU (bench.py default: pipeline mode, the Gram on its 224-CU stream, two "
+                            "launches, unpaced)",
+                   method="2*FETCH_SIZE*1024 + WRITE_SIZE*1024, separate --pmc passes, summed over the launches of one Gram")
+        if "whole_chip" in old:
+            rec["whole_chip"] = old["whole_chip"]
+        with open(tfile, "w") as fp:
+            json.dump(rec, fp, indent=1)
+    if gram and "_benchlat_" in a.tag:   # bench.py --mode latency: the Gram of a single POD, all 256 CUs (one launch, paced)
+        rec = json.load(open(tfile)) if os.path.exists(tfile) else {}
+        rec["whole_chip"] = dict(hbm_bytes_per_gram=sum(gram), source=f"profiles/{a.tag}_pmc.json",
+                                 kernels=sorted(k for k in pmc if k.startswith("gram128_")),
+                                 workload="pod_1000000x512, bench.py --mode latency (one POD after the other on the whole chip)")
+        with open(tfile, "w") as fp:
+            json.dump(rec, fp, indent=1)
     proj = [cs for k, cs in pmc.items() if k.startswith("project_fused_kernel<5, false>") and "hbm_bytes_per_launch" in cs]
     if proj and "_c5sweep_" in a.tag:  # the projection launch of the direct sweep (32 value vectors, r = 80, N = 1e5)
         with open(os.path.join(ROOT, "profiles", "project_traffic.json"), "w") as fp:
