@@ -446,10 +446,13 @@ def main():
             latency_ms = 1e3 * (time.perf_counter() - t1) / 5
             # the Gram kernel on the whole chip (what a single POD runs: one launch, paced - see DESIGN section 4), its
             # own HIP event pair on the ctx stream
+            # (sustained: the event pair of the last of eight launches back to back - a launch on its own, or the first after
+            # an eigensolve during which 7/8 of the chip idled, runs ~8 % longer at the clock it finds)
             ctx.set_profile(True)
             whole = []
-            for _ in range(5):
-                ops.gram(X)
+            for _ in range(3):
+                for _ in range(8):
+                    ops.gram(X)
                 torch.cuda.synchronize()
                 whole.append(ctx.last_gram_ms())
             ctx.set_profile(False)
