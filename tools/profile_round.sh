@@ -46,6 +46,6 @@ done
 python3 tools/summarize_prof.py ${ROUND}_c4_${TAG} --stats $O/c4_stats --fetch $O/c4_fetch --write $O/c4_write --sq $O/c4_sq --keep $KEEP || exit 32
 python3 tools/summarize_prof.py ${ROUND}_sweep_${TAG} --stats $O/sweep_stats || exit 10
 python3 tools/summarize_prof.py ${ROUND}_hsweep_${TAG} --stats $O/hsweep_stats || exit 11
-cp profiles/${ROUND}_*_${TAG}* profiles/gram_traffic.json $DEST/
+cp profiles/${ROUND}_*_${TAG}* profiles/gram_traffic.json profiles/project_traffic.json $DEST/
 rm -f $DEST/*_sweep_${TAG}_pmc.json $DEST/*_hsweep_${TAG}_pmc.json; rm -rf $O/lat_stats $O/lat_fetch $O/lat_write $O/stats $O/fetch $O/write $O/sq $O/sweep_stats $O/hsweep_stats $O/c4_stats $O/*_fetch $O/*_write $O/*_sq   # raw output is large; the summaries are what is kept
 ls -la $DEST
