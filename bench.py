@@ -410,7 +410,8 @@ def main():
                 # gloo rehearsal, ranks sharing a GPU: every rank's eigensolver team needs CUs of its own
                 pipe = PodPipeline(group=group, eig_first_cu=4 * local_rank, gram_range=(4 * world, 32 - 4 * world))
             else:
-                pipe = PodPipeline(group=group)
+                # ROMTIME_PIPELINE_EIG_CUS: experiments with the CU partition (CUs of every XCD given to the eigensolver stream)
+                pipe = PodPipeline(group=group, eig_cus_per_xcd=int(os.environ.get("ROMTIME_PIPELINE_EIG_CUS", "4")))
         except Exception as exc:  # noqa: BLE001  (a host that refuses CU-masked queues: one POD after the other instead)
             if args.mode == "pipeline":
                 raise

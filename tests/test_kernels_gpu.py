@@ -47,7 +47,11 @@ def test_gram_long_sets(ops, N, n, order):
     Xh[:, n // 2] *= 1e3                                     # a misplaced column would show
     X = ops.to_device(np.asfortranarray(Xh) if order == "F" else Xh)
     G = ops.gram(X)
-    assert Context.current().launch_info()["tile"] == (128, 128)
+    info = Context.current().launch_info()
+    assert info["tile"] == (128, 128)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    one_launch = info["grid"] == 2 * cus          # the one-launch kernel always launches every slot of the chip
+    assert one_launch == (n in (200, 250, 384, 500, 512, 1000)), (n, info)
     assert torch.equal(G, G.T)
     assert _rel(G.cpu().numpy(), Xh.T @ Xh) < 5e-14
     assert torch.equal(G, ops.gram(X))
