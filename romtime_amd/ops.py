@@ -21,8 +21,14 @@ def _ptr(t):
     return _p(t.data_ptr()) if t is not None else _p(None)
 
 
+def _need_gpu():
+    if not torch.cuda.is_available():
+        raise RomtimeHipError("no MI355X visible: romtime_amd's hot path runs on the GPU only (there is no CPU fallback)")
+
+
 def to_device(a, device=None) -> torch.Tensor:
     """NumPy (or tensor) -> float64 CUDA tensor with the same logical shape and memory order."""
+    _need_gpu()
     if isinstance(a, torch.Tensor):
         t = a.to(dtype=torch.float64)
         return t.cuda(device) if not t.is_cuda else t
@@ -33,6 +39,7 @@ def to_device(a, device=None) -> torch.Tensor:
 
 
 def to_device_index(a, device=None) -> torch.Tensor:
+    _need_gpu()
     return torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.int64))).cuda(device)
 
 

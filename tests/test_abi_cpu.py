@@ -30,3 +30,21 @@ def test_header_cites_reference_for_each_hot_entry_point():
     text = open(os.path.join(REPO, "include", "romtime_hip.h")).read()
     for needle in ("pod.py", "deim.py:517-561", "utils.py:96-113", "mdeim.py:153-192", "rom.py"):
         assert needle in text
+
+
+def test_package_shutdown_is_harmless_without_a_gpu_and_twice():
+    """romtime_amd.shutdown() releases device state in order; with nothing created (no GPU here) it is a no-op, also
+    when called again, and the hot path still refuses to run without a GPU afterwards."""
+    import numpy as np
+    import pytest
+    import torch
+
+    import romtime_amd
+    from romtime_amd._lib import Context, RomtimeHipError
+
+    romtime_amd.shutdown()
+    romtime_amd.shutdown()
+    assert len(Context._live) == 0
+    if not torch.cuda.is_available():
+        with pytest.raises(RomtimeHipError):
+            romtime_amd.orth(np.ones((8, 3)))
