@@ -251,9 +251,10 @@ __global__ __launch_bounds__(RES_THREADS) void deim_column_kernel(double* __rest
 //        W = L21 Linv[:kb,:kb],  L21[i][q] = r_q[p_i] / delta_q  (i in P, q < kb),
 //        Linv[i][j] = -(W[i][j] + sum_{q in P, q < i} l_iq Linv[q][j])   (the step-by-step recurrence, row by row);
 //   c. coefficients of the new block's columns against everything before it:
-//        YT[c - k0][i] = (Linv[:k0,:k0] b_c)_i / delta_i,   b_c[i] = phi_c[p_i]   (column c of R still holds phi_c).
+//        YT[c - k0][i] = (Linv[:k0,:k0] b_c)_i / delta_i,   b_c[i] = phi_c[p_i]   (read from the caller's Phi).
 __global__ __launch_bounds__(PIV_THREADS) void deim_block_start_kernel(const double* R, long ldr, int k0, int kb, int nb,
-                                                                       StepState st, double* __restrict__ YT) {
+                                                                       StepState st, double* __restrict__ YT,
+                                                                       const double* __restrict__ Phi, long ld, int layout) {
   constexpr int CG = 4;  // columns per pass over L^-1 (each row of L^-1 is read once per pass)
   __shared__ StepShared sh;
   __shared__ double s_b[BLK][1024];      // phase b: partial sums of W; phase c: rows [0, CG) = b_c
@@ -320,7 +321,8 @@ __global__ __launch_bounds__(PIV_THREADS) void deim_block_start_kernel(const dou
     for (int i = tid; i < k0; i += PIV_THREADS) {
       const long p = st.idx[i];
 #pragma unroll
-      for (int c = 0; c < CG; ++c) s_b[c][i] = (c0 + c < nb) ? R[(long)(k0 + c0 + c) * ldr + p] : 0.0;
+      for (int c = 0; c < CG; ++c)   // phi_c at the pivot rows, from the caller's basis
+        s_b[c][i] = (c0 + c < nb) ? (layout == RT_COL_MAJOR ? Phi[(long)(k0 + c0 + c) * ld + p] : Phi[p * ld + k0 + c0 + c]) : 0.0;
     }
     __syncthreads();
     for (int i = wid; i < k0; i += PIV_THREADS / 64) {
@@ -348,7 +350,8 @@ __global__ __launch_bounds__(PIV_THREADS) void deim_block_start_kernel(const dou
 // reads what it writes.  k0 = 0: a copy of the first block's columns.
 __global__ __launch_bounds__(RES_THREADS) void deim_phase_a_kernel(const double* __restrict__ R, double* __restrict__ Tb,
                                                                    long ldr, long N, int k0, int nb, int m,
-                                                                   const double* __restrict__ YT) {
+                                                                   const double* __restrict__ YT,
+                                                                   const double* __restrict__ Phi, long ld, int layout) {
   extern __shared__ double s_yt[];  // [k0][BLK]
   const int tid = threadIdx.x;
   for (int q = tid; q < k0 * BLK; q += RES_THREADS) {
@@ -372,43 +375,46 @@ __global__ __launch_bounds__(RES_THREADS) void deim_phase_a_kernel(const double*
       acc[c].y = fma(a.y, y[c], acc[c].y);
     }
   }
+  // phi_c comes straight from the caller's basis, in its own layout (row-major: the block's 8 columns are 64 contiguous
+  // bytes of a row) - R is never initialised with a transposed copy of Phi (that copy was 0.19 of C4's 2.5 ms)
+  const bool two = row + 1 < N;
+  double p0[BLK], p1[BLK];
+  if (layout == RT_COL_MAJOR) {
+#pragma unroll
+    for (int c = 0; c < BLK; ++c) {
+      const double* src = Phi + (long)(k0 + (c < nb ? c : 0)) * ld + row;
+      p0[c] = src[0];
+      p1[c] = two ? src[1] : 0.0;
+    }
+  } else {
+    const double* s0 = Phi + row * ld + k0;
+    const double* s1 = s0 + (two ? ld : 0);
+    if (nb == BLK && ((ld | k0) & 1) == 0 && (reinterpret_cast<size_t>(Phi) & 15) == 0) {
+#pragma unroll
+      for (int c = 0; c < BLK; c += 2) {
+        const d2 a = *reinterpret_cast<const d2*>(s0 + c), b = *reinterpret_cast<const d2*>(s1 + c);
+        p0[c] = a.x; p0[c + 1] = a.y;
+        p1[c] = two ? b.x : 0.0; p1[c + 1] = two ? b.y : 0.0;
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < BLK; ++c) {
+        const int cc = c < nb ? c : 0;
+        p0[c] = s0[cc];
+        p1[c] = two ? s1[cc] : 0.0;
+      }
+    }
+  }
 #pragma unroll
   for (int c = 0; c < BLK; ++c) {
     if (c < nb) {
-      d2 r = *reinterpret_cast<const d2*>(R + (long)(k0 + c) * ldr + row);
-      r.x -= acc[c].x;
-      r.y -= acc[c].y;
+      d2 r{p0[c] - acc[c].x, p1[c] - acc[c].y};
       *reinterpret_cast<d2*>(Tb + (long)c * ldr + row) = r;
     }
   }
 }
 
-// R (column-major, ldr) <- Phi in either layout
-__global__ void deim_copy_in_kernel(const double* __restrict__ Phi, long ld, int layout, long N, int m,
-                                    double* __restrict__ R, long ldr) {
-  __shared__ double tile[32][33];
-  if (layout == RT_COL_MAJOR) {
-    const long i = (long)blockIdx.x * blockDim.x * blockDim.y + threadIdx.y * blockDim.x + threadIdx.x;
-    const int j = blockIdx.y;
-    if (i < ldr) R[(long)j * ldr + i] = (i < N) ? Phi[(long)j * ld + i] : 0.0;
-    return;
-  }
-  // row-major: 32x32 tile transpose; blockIdx.x -> row tile, blockIdx.y -> column tile
-  const long i0 = (long)blockIdx.x * 32;
-  const int j0 = blockIdx.y * 32;
-  for (int rr = threadIdx.y; rr < 32; rr += blockDim.y) {
-    const long i = i0 + rr;
-    const int j = j0 + threadIdx.x;
-    tile[rr][threadIdx.x] = (i < N && j < m) ? Phi[i * ld + j] : 0.0;
-  }
-  __syncthreads();
-  for (int cc = threadIdx.y; cc < 32; cc += blockDim.y) {
-    const int j = j0 + cc;
-    const long i = i0 + threadIdx.x;
-    if (j < m && i < ldr) R[(long)j * ldr + i] = tile[threadIdx.x][cc];
-  }
-}
-
+// PT_U[i][j] = Phi[p_i][j]
 __global__ void deim_gather_ptu_kernel(const double* __restrict__ Phi, long ld, int layout, int m,
                                        const long* __restrict__ idx, double* __restrict__ PT_U) {
   const int i = blockIdx.x;
@@ -453,15 +459,6 @@ extern "C" int rt_deim_greedy(rt_ctx* ctx, const double* Phi, int64_t N, int64_t
   hipStream_t st = ctx->stream;
 
   RT_HIP_CHECK(ctx, hipMemsetAsync(Linv, 0, sizeof(double) * m * m, st));
-  if (layout == RT_COL_MAJOR) {
-    dim3 grid((unsigned)((ldr + 255) / 256), (unsigned)m);
-    hipLaunchKernelGGL(deim_copy_in_kernel, grid, dim3(64, 4), 0, st, Phi, (long)ld, layout, (long)N, (int)m, R, ldr);
-  } else {
-    dim3 grid((unsigned)((ldr + 31) / 32), (unsigned)((m + 31) / 32));
-    hipLaunchKernelGGL(deim_copy_in_kernel, grid, dim3(32, 8), 0, st, Phi, (long)ld, layout, (long)N, (int)m, R, ldr);
-  }
-  RT_HIP_CHECK(ctx, hipGetLastError());
-
   // Blocked left-looking elimination: per block of BLK columns one serial kernel (finish the block before, block
   // coefficients) and one sweep (phase A) that applies all earlier residual columns, then one launch per column:
   // the column's kernel finishes the step before it in every workgroup and reduces the column against at most
@@ -472,15 +469,17 @@ extern "C" int rt_deim_greedy(rt_ctx* ctx, const double* Phi, int64_t N, int64_t
   for (int k0 = 0; k0 < (int)m; k0 += BLK) {
     const int nb = ((int)m - k0 < BLK) ? (int)m - k0 : BLK;
     if (k0 > 0)
-      hipLaunchKernelGGL(deim_block_start_kernel, dim3(1), dim3(PIV_THREADS), 0, st, R, ldr, k0, k0 - BLK, nb, state, YT);
+      hipLaunchKernelGGL(deim_block_start_kernel, dim3(1), dim3(PIV_THREADS), 0, st, R, ldr, k0, k0 - BLK, nb, state, YT, Phi,
+                         (long)ld, layout);
     hipLaunchKernelGGL(deim_phase_a_kernel, dim3(nparts), dim3(RES_THREADS), sizeof(double) * k0 * BLK, st, R, Tb, ldr,
-                       (long)N, k0, nb, (int)m, YT);
+                       (long)N, k0, nb, (int)m, YT, Phi, (long)ld, layout);
     for (int k = k0; k < k0 + nb; ++k)
       hipLaunchKernelGGL(deim_column_kernel, dim3(ncol), dim3(RES_THREADS), 0, st, R, Tb, ldr, (long)N, k, k0, state);
   }
   {  // the last step
     const int kb = ((int)m - 1) / BLK * BLK;
-    hipLaunchKernelGGL(deim_block_start_kernel, dim3(1), dim3(PIV_THREADS), 0, st, R, ldr, (int)m, kb, 0, state, YT);
+    hipLaunchKernelGGL(deim_block_start_kernel, dim3(1), dim3(PIV_THREADS), 0, st, R, ldr, (int)m, kb, 0, state, YT, Phi,
+                       (long)ld, layout);
   }
   RT_HIP_CHECK(ctx, hipGetLastError());
   if (PT_U) {

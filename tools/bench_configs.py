@@ -119,7 +119,8 @@ def c4():
     Phi = out["Q"]
     ms_greedy, g = wall_time(lambda: ops.deim_greedy(Phi, want_margin=False), reps=2)
     greedy_bytes = 8.0 * nnz * sum(k + 2 for k in range(m))      # reference algorithm: step k reads k+1 columns
-    L = 8                                                        # blocked elimination actually moves about this much
+    L = 8                                                        # blocked elimination actually moves about this much:
+    # m^2/(2L) columns read by the block sweeps, 2m for their phi columns in / t columns out, (L+3)/2 per column launch
     greedy_bytes_blocked = 8.0 * nnz * (m * m / (2.0 * L) + 2 * m + m * (L + 3) / 2.0)
     V, _ = torch.linalg.qr(torch.randn((N, r), dtype=torch.float64, device="cuda"))
     ip, ix = ops.to_device_index(A.indptr), ops.to_device_index(A.indices)
