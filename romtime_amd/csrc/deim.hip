@@ -255,7 +255,7 @@ __global__ __launch_bounds__(RES_THREADS) void deim_column_kernel(double* __rest
 __global__ __launch_bounds__(PIV_THREADS) void deim_block_start_kernel(const double* R, long ldr, int k0, int kb, int nb,
                                                                        StepState st, double* __restrict__ YT,
                                                                        const double* __restrict__ Phi, long ld, int layout) {
-  constexpr int CG = 4;  // columns per pass over L^-1 (each row of L^-1 is read once per pass)
+  constexpr int CG = BLK;  // columns per pass over L^-1: the whole block (one pass; two passes of 4 read every row twice)
   __shared__ StepShared sh;
   __shared__ double s_b[BLK][1024];      // phase b: partial sums of W; phase c: rows [0, CG) = b_c
   __shared__ double s_l21[BLK][1024];
@@ -325,11 +325,19 @@ __global__ __launch_bounds__(PIV_THREADS) void deim_block_start_kernel(const dou
         s_b[c][i] = (c0 + c < nb) ? (layout == RT_COL_MAJOR ? Phi[(long)(k0 + c0 + c) * ld + p] : Phi[p * ld + k0 + c0 + c]) : 0.0;
     }
     __syncthreads();
+    // a wave's rows in turn; the first 64 entries of the NEXT row are fetched before this row's sums are reduced (the
+    // loads of a row used to start only after the wave-wide reductions of the row before: ~1 us of L2 latency per row)
+    double l_next = (wid < k0 && lane <= wid) ? st.Linv[(long)wid * m + lane] : 0.0;
     for (int i = wid; i < k0; i += PIV_THREADS / 64) {
       double acc[CG];
+      const double l_first = l_next;
+      {
+        const int in = i + PIV_THREADS / 64;
+        l_next = (in < k0 && lane <= in) ? st.Linv[(long)in * m + lane] : 0.0;
+      }
 #pragma unroll
-      for (int c = 0; c < CG; ++c) acc[c] = 0.0;
-      for (int j = lane; j <= i; j += 64) {
+      for (int c = 0; c < CG; ++c) acc[c] = (lane <= i) ? l_first * s_b[c][lane] : 0.0;
+      for (int j = lane + 64; j <= i; j += 64) {
         const double l = st.Linv[(long)i * m + j];
 #pragma unroll
         for (int c = 0; c < CG; ++c) acc[c] = fma(l, s_b[c][j], acc[c]);
