@@ -214,6 +214,26 @@ def test_greedy_random(ops, N, m):
     assert list(idx2.cpu().numpy()) == list(dofs)
 
 
+@pytest.mark.parametrize("N,m", [(7001, 20), (12000, 33)])
+def test_greedy_reads_the_basis_where_it_lies(ops, N, m):
+    """The basis is never copied: phase A and the block starts read it in the caller's layout - here a column slice of a
+    wider row-major buffer (odd leading dimension, unaligned first column: scalar loads) and a slice of a column-major
+    buffer with a padded leading dimension."""
+    rng = np.random.RandomState(N + m)
+    B, _ = np.linalg.qr(rng.standard_normal((N, m)))
+    dofs, PT_U, _ = oracle.deim_greedy(B)
+    wide = np.zeros((N, m + 7))
+    wide[:, 3:3 + m] = B
+    idx, PT_U_d, _ = ops.deim_greedy(ops.to_device(wide)[:, 3:3 + m])
+    assert list(idx.cpu().numpy()) == list(dofs)
+    np.testing.assert_array_equal(PT_U_d.cpu().numpy(), PT_U)
+    tall = np.zeros((m + 2, N + 5))
+    tall[1:1 + m, 2:2 + N] = B.T
+    idx2, PT_U_d2, _ = ops.deim_greedy(ops.to_device(tall)[1:1 + m, 2:2 + N].T)
+    assert list(idx2.cpu().numpy()) == list(dofs)
+    np.testing.assert_array_equal(PT_U_d2.cpu().numpy(), PT_U)
+
+
 def test_greedy_more_workgroups_than_the_chip_holds(ops):
     """N = 3e6: a column's kernel has 2930 workgroups, more than one round of resident ones (256 CUs x 8), so late
     workgroups of a launch start after early ones have finished.  Every workgroup finishes the step before for itself
