@@ -29,6 +29,7 @@
 //
 // Output: per-(XCD, segment) 128x128 slabs, summed in a fixed order by gram_reduce_kernel
 // (bitwise reproducible; exactly symmetric G).
+#include <algorithm>
 #include <cstdlib>
 #include <type_traits>
 
@@ -392,12 +393,13 @@ int launch_gram(rt_ctx* ctx, const GramParams& p, int grid) {
 // Fills the segments, the slab index of every segment and the per-tile slab lists of the reduction.
 // Slots per off-diagonal (a) and per diagonal tile (b) of the uniform plan below; returns the slowest slot's time per
 // stage of the range, max(1/a, rho/b), or 0 when there is no such plan.
-double gram_uniform_ab(int P, int n_off, int n_d, double rho, int* a_out, int* b_out) {
+// `cap`: most slots a tile may get (short sets: at least 48 stages per workgroup).
+double gram_uniform_ab(int P, int n_off, int n_d, double rho, int cap, int* a_out, int* b_out) {
   double best = 1e30;
   int best_slots = 0;
   *a_out = *b_out = 0;
-  for (int a = 1; n_off * a + n_d <= P; ++a)
-    for (int b = 1; n_off * a + n_d * b <= P; ++b) {
+  for (int a = 1; a <= cap && n_off * a + n_d <= P; ++a)
+    for (int b = 1; b <= cap && n_off * a + n_d * b <= P; ++b) {
       const double T = (1.0 / a > rho / b) ? 1.0 / a : rho / b;
       const int used = n_off * a + n_d * b;
       if (T < best - 1e-12 || (T < best + 1e-12 && used < best_slots)) { best = T; *a_out = a; *b_out = b; best_slots = used; }
@@ -419,7 +421,7 @@ bool gram_plan(int P, int tiles1, int nst, double rho, GramSegs& g, unsigned cha
   int uni_b = 0;
   if (uniform) {
     int best_a = 0;
-    if (gram_uniform_ab(P, n_off, n_d, rho, &best_a, &uni_b) <= 0.0) return false;
+    if (gram_uniform_ab(P, n_off, n_d, rho, nst / 48, &best_a, &uni_b) <= 0.0) return false;
     S_off = best_a;
   }
   if (S_off < 1 || nst < 48 * S_off) return false;   // short sets: the two-launch form with its own caps
@@ -566,16 +568,23 @@ int rt_gram128(rt_ctx* ctx, const double* X, int64_t ks, int64_t ms, int64_t K, 
   static const int rho_pct = [] { const char* e = getenv("ROMTIME_GRAM_RHO"); return e ? atoi(e) : 60; }();
   // ---- which plan --------------------------------------------------------------------------------------------------------
   // One launch with uniform slots reads X once (4.15 GB on 1e6 x 512 against 8.2 for two paced launches and 14.5 unpaced)
-  // but leaves slots idle part of the time; it is taken when pacing is on and the model says it costs at most 5 % more
+  // but leaves slots idle part of the time; it is taken when the model says it costs at most 5 % more
   // than two launches - where it then measured 1-6 % FASTER (n = 256, 384, 512, 1024: tools/probes/gram_shapes.py);
   // n = 640 / 768 (model 1.15 / 1.07, measured 1.12 / 1.05) and the pipeline's 56 slots (1.08, measured 1.08) stay with
   // two launches.  ROMTIME_GRAM_FLAGS & 256 forces it, & 512 forbids it.
   bool uniform = (env_flags & 256) != 0;
-  if (!uniform && !(env_flags & (16 | 512)) && n_off >= 1 && p.pace) {
+  if (!uniform && !(env_flags & (16 | 512)) && n_off >= 1) {   // (whatever "gram_pace" says: the option must not change a bit of G)
     int a = 0, b = 0;
-    const double t_uni = gram_uniform_ab(slots_max, n_off, tiles1, rho_pct / 100.0, &a, &b);
-    const double t_two = 1.0 / (slots_max / n_off) + (rho_pct / 100.0) / (slots_max / tiles1);
-    uniform = t_uni > 0.0 && t_uni <= 1.05 * t_two;
+    // short sets: no tile gets more slots than leave 48 stages per workgroup, in either form - two launches then fill
+    // the chip poorly one after the other (1e5 x 256: 128 + 256 workgroups), one launch runs all tiles side by side
+    const int cap = (int)(p.kx / KB / 48);
+    const double t_uni = gram_uniform_ab(slots_max, n_off, tiles1, rho_pct / 100.0, cap, &a, &b);
+    const int s_off2 = std::min(slots_max / n_off, cap), s_diag2 = std::min(slots_max / tiles1, cap);
+    const double t_two = (s_off2 >= 1 && s_diag2 >= 1) ? 1.0 / s_off2 + (rho_pct / 100.0) / s_diag2 : 0.0;
+    // (measured, tools/probes/gram_shapes.py short: 5e4 x 512 0.276 vs 0.306 ms, 3e4 x 384 0.164 vs 0.190, 1e5 x 384 0.321 vs
+    // 0.383, 2.5e5 x 200 0.372 vs 0.446, 6e4 x 1000 1.09 vs 1.13; but 1e5 x 256 / 200, one off-diagonal tile whose 29 slots
+    // the cap cuts to 16: 0.219 vs 0.209 - a two-tile-column set keeps two launches while the cap binds)
+    uniform = t_uni > 0.0 && t_two > 0.0 && t_uni <= 1.05 * t_two && n_off * a + tiles1 * b >= 16 && !(tiles1 == 2 && a >= cap);
   }
   if (((env_flags & 16) || uniform) && n_off >= 1) {
     GramSegs g;

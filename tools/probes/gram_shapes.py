@@ -10,7 +10,9 @@ from romtime_amd import ops  # noqa: E402
 from romtime_amd._lib import Context  # noqa: E402
 
 tag = os.environ.get("ROMTIME_GRAM_FLAGS", "-") + ":" + os.environ.get("ROMTIME_GRAM_PACE", "-")
-for (N, n, order) in [(1_000_000, 512, "C"), (1_000_000, 384, "C"), (1_000_000, 256, "C"), (600_000, 640, "C"),
+SHORT = [(100_000, 256, "C"), (100_000, 200, "C"), (50_000, 512, "C"), (30_000, 384, "C"), (200_000, 256, "C"), (100_000, 384, "C"),
+         (60_000, 1000, "C"), (100_000, 256, "F"), (250_000, 200, "C")]
+for (N, n, order) in SHORT if "short" in sys.argv else [(1_000_000, 512, "C"), (1_000_000, 384, "C"), (1_000_000, 256, "C"), (600_000, 640, "C"),
                       (500_000, 768, "C"), (400_000, 1024, "C"), (1_000_000, 500, "C"), (300_000, 512, "C"),
                       (1_000_000, 512, "F")]:
     X = torch.randn((N, n) if order == "C" else (n, N), dtype=torch.float64, device="cuda")
