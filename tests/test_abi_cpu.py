@@ -48,3 +48,18 @@ def test_package_shutdown_is_harmless_without_a_gpu_and_twice():
     if not torch.cuda.is_available():
         with pytest.raises(RomtimeHipError):
             romtime_amd.orth(np.ones((8, 3)))
+
+
+def test_header_documents_every_context_option_and_counter():
+    """Every name rt_ctx_set_option / rt_ctx_get_counter accepts (csrc/api.hip) appears in include/romtime_hip.h."""
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "romtime_amd", "csrc", "api.hip")).read()
+    header = open(os.path.join(root, "include", "romtime_hip.h")).read()
+    options = set(re.findall(r'key == "([a-z_0-9]+)"', src))
+    counters = set(re.findall(r'\{"([a-z_0-9]+)", RT_CNT_', src))
+    assert {"gram_pace", "cu_limit", "eig_xcd", "eig_one_xcd", "sweep_graph"} <= options
+    missing = [name for name in sorted(options | counters) if f'"{name}"' not in header]
+    assert not missing, f"undocumented in include/romtime_hip.h: {missing}"
