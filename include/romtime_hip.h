@@ -85,6 +85,11 @@ int rt_ctx_get_counter(rt_ctx* ctx, const char* name, int64_t* value);
 /* The same for the most recent launch of the snapshot Gram kernel (rt_gram, n >= 97, long X): its own event pair,
  * so it can be read at the end of a POD step, after the GEMMs that followed it, without holding the host back. */
 int rt_last_gram_ms(rt_ctx* ctx, double* ms);
+/* Which form rt_gram takes for an n_rows x n_cols snapshot set on num_cus compute units (host logic only, no GPU needed:
+ * diagnostics and the CPU-side tests): out[0] = 0 the generic symmetric GEMM, 1 two launches (out[3] / out[4] sub-splits
+ * per off-diagonal / diagonal tile and XCD), 2 one launch with uniform slots (out[1] / out[2] per tile) whose paced
+ * workgroups read the snapshots once. */
+int rt_gram_plan_info(int num_cus, int64_t n_rows, int64_t n_cols, int* out);
 
 /* ---- POD (src/romtime/rom/pod.py:7-62) ------------------------------------------------ */
 

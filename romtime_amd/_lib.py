@@ -35,6 +35,7 @@ SIGNATURES = {
     "rt_ctx_set_option": (_int, [_p, C.c_char_p, _int]),
     "rt_last_gemm_ms": (_int, [_p, C.POINTER(C.c_double)]),
     "rt_last_gram_ms": (_int, [_p, C.POINTER(C.c_double)]),
+    "rt_gram_plan_info": (_int, [_int, _i64, _i64, C.POINTER(_int)]),
     "rt_ctx_get_counter": (_int, [_p, C.c_char_p, C.POINTER(_i64)]),
     "rt_stream_create_cu_range": (_int, [_int, _int, _int, C.POINTER(_p)]),
     "rt_stream_destroy": (_int, [_p]),

@@ -502,6 +502,38 @@ bool gram_plan(int P, int tiles1, int nst, double rho, GramSegs& g, unsigned cha
   return uniform ? slot <= P : slot == P;
 }
 
+// Which form the snapshot Gram takes for a K x n set on `num_cus` CUs - pure host logic, no GPU (rt_gram_plan_info lets
+// the CPU-side tests check it).  form 0: not this kernel (the generic symmetric GEMM), 1: two launches (S_off / S_diag
+// sub-splits per off-diagonal / diagonal tile and XCD), 2: one launch with uniform slots (a / b per tile).
+struct GramChoice {
+  int form, a, b, s_off, s_diag;
+};
+GramChoice gram_choose(int num_cus, long K, long n, double rho, int slots_per_cu = 2) {
+  GramChoice c{0, 0, 0, 0, 0};
+  const int tiles1 = (int)((n + BT - 1) / BT), ntiles = tiles1 * (tiles1 + 1) / 2, n_off = ntiles - tiles1;
+  const int slots_max = slots_per_cu * num_cus / 8;
+  if (n < 97 || ntiles > MAX_TILES || n_off > slots_max || slots_max > MAX_SLOTS || K < 8L * 64 * KB) return c;
+  const long kx = ((K + 7) / 8 + KB - 1) / KB * KB;
+  const int cap = (int)(kx / KB / 48);   // no tile gets more slots than leave 48 stages per workgroup
+  if (cap < 1) return c;
+  c.s_off = n_off ? std::min(slots_max / n_off, cap) : 0;
+  c.s_diag = std::min(slots_max / tiles1, cap);
+  if (n_off >= 1) {
+    // One launch with uniform slots reads X once but leaves slots idle part of the time; taken when the slot model says
+    // it costs at most 5 % more than two launches (measured 1-17 % faster there, profiles/r03_gram_pace_ab.txt), with at
+    // least 16 workgroups per XCD, and not for two-tile-column sets while the cap binds (1e5 x 256: 0.219 vs 0.209 ms)
+    const double t_uni = gram_uniform_ab(slots_max, n_off, tiles1, rho, cap, &c.a, &c.b);
+    const double t_two = (c.s_off >= 1 && c.s_diag >= 1) ? 1.0 / c.s_off + rho / c.s_diag : 0.0;
+    if (t_uni > 0.0 && t_two > 0.0 && t_uni <= 1.05 * t_two && n_off * c.a + tiles1 * c.b >= 16 && !(tiles1 == 2 && c.a >= cap)) {
+      c.form = 2;
+      return c;
+    }
+  }
+  const int busiest = n_off ? n_off * c.s_off : tiles1 * c.s_diag;
+  c.form = (busiest >= 16) ? 1 : 0;
+  return c;
+}
+
 template <bool KC>
 int launch_gram_merged(rt_ctx* ctx, const GramParams& p, const GramSegs& g, int grid) {
   constexpr size_t lds = sizeof(double) * 4 * Panel<BT, KC, GT>::LDS;
@@ -573,19 +605,8 @@ int rt_gram128(rt_ctx* ctx, const double* X, int64_t ks, int64_t ms, int64_t K, 
   // n = 640 / 768 (model 1.15 / 1.07, measured 1.12 / 1.05) and the pipeline's 56 slots (1.08, measured 1.08) stay with
   // two launches.  ROMTIME_GRAM_FLAGS & 256 forces it, & 512 forbids it.
   bool uniform = (env_flags & 256) != 0;
-  if (!uniform && !(env_flags & (16 | 512)) && n_off >= 1) {   // (whatever "gram_pace" says: the option must not change a bit of G)
-    int a = 0, b = 0;
-    // short sets: no tile gets more slots than leave 48 stages per workgroup, in either form - two launches then fill
-    // the chip poorly one after the other (1e5 x 256: 128 + 256 workgroups), one launch runs all tiles side by side
-    const int cap = (int)(p.kx / KB / 48);
-    const double t_uni = gram_uniform_ab(slots_max, n_off, tiles1, rho_pct / 100.0, cap, &a, &b);
-    const int s_off2 = std::min(slots_max / n_off, cap), s_diag2 = std::min(slots_max / tiles1, cap);
-    const double t_two = (s_off2 >= 1 && s_diag2 >= 1) ? 1.0 / s_off2 + (rho_pct / 100.0) / s_diag2 : 0.0;
-    // (measured, tools/probes/gram_shapes.py short: 5e4 x 512 0.276 vs 0.306 ms, 3e4 x 384 0.164 vs 0.190, 1e5 x 384 0.321 vs
-    // 0.383, 2.5e5 x 200 0.372 vs 0.446, 6e4 x 1000 1.09 vs 1.13; but 1e5 x 256 / 200, one off-diagonal tile whose 29 slots
-    // the cap cuts to 16: 0.219 vs 0.209 - a two-tile-column set keeps two launches while the cap binds)
-    uniform = t_uni > 0.0 && t_two > 0.0 && t_uni <= 1.05 * t_two && n_off * a + tiles1 * b >= 16 && !(tiles1 == 2 && a >= cap);
-  }
+  if (!uniform && !(env_flags & (16 | 512)) && !occ1)   // (whatever "gram_pace" says: the option must not change a bit of G)
+    uniform = gram_choose(ctx->num_cus, (long)K, (long)n, rho_pct / 100.0).form == 2;
   if (((env_flags & 16) || uniform) && n_off >= 1) {
     GramSegs g;
     GramReduceParams rp;
@@ -710,5 +731,13 @@ int rt_gram128(rt_ctx* ctx, const double* X, int64_t ks, int64_t ms, int64_t K, 
   const long total = n * n;
   hipLaunchKernelGGL(gram_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, rp);
   RT_HIP_CHECK(ctx, hipGetLastError());
+  return RT_OK;
+}
+
+// Diagnostic / test hook: the form rt_gram would take (gram_choose) - out = {form, a, b, S_off, S_diag}.  No GPU needed.
+extern "C" int rt_gram_plan_info(int num_cus, int64_t n_rows, int64_t n_cols, int* out) {
+  if (!out || num_cus < 8 || n_rows < 1 || n_cols < 1) return RT_ERR_ARG;
+  const GramChoice c = gram_choose(num_cus, (long)n_rows, (long)n_cols, 0.60);
+  out[0] = c.form; out[1] = c.a; out[2] = c.b; out[3] = c.s_off; out[4] = c.s_diag;
   return RT_OK;
 }

@@ -63,3 +63,29 @@ def test_header_documents_every_context_option_and_counter():
     assert {"gram_pace", "cu_limit", "eig_xcd", "eig_one_xcd", "sweep_graph"} <= options
     missing = [name for name in sorted(options | counters) if f'"{name}"' not in header]
     assert not missing, f"undocumented in include/romtime_hip.h: {missing}"
+
+
+def test_gram_plan_choice_is_host_logic_and_matches_the_measured_rules():
+    """rt_gram_plan_info: the form rt_gram takes (no GPU needed).  One paced launch with uniform slots where the slot model
+    puts it within 5 % of two launches (profiles/r03_gram_pace_ab.txt), two launches elsewhere, the
+    generic GEMM outside the kernel's range."""
+    import ctypes as C
+
+    from romtime_amd import _lib
+
+    lib = _lib.load()
+
+    def plan(cus, rows, cols):
+        out = (C.c_int * 5)()
+        assert lib.rt_gram_plan_info(cus, rows, cols, out) == 0
+        return tuple(out)
+
+    assert plan(256, 1_000_000, 512)[:3] == (2, 7, 5)            # bench shape on the whole chip: 62 of 64 slots
+    assert plan(256, 1_000_000, 500)[:3] == (2, 7, 5)
+    assert plan(256, 1_000_000, 384)[0] == 2 and plan(256, 1_000_000, 256)[0] == 2 and plan(256, 400_000, 1024)[:3] == (2, 2, 1)
+    assert plan(256, 600_000, 640)[0] == 1 and plan(256, 500_000, 768)[0] == 1     # model 1.15 / 1.07: two launches
+    assert plan(224, 1_000_000, 512) == (1, 6, 4, 9, 14)          # the POD pipeline's 224-CU stream: 56 slots, two launches
+    assert plan(256, 100_000, 256) == (1, 16, 10, 16, 16)         # two tile columns, cap binding: two launches (C2)
+    assert plan(256, 200_000, 256)[0] == 2 and plan(256, 50_000, 512)[:3] == (2, 7, 5) and plan(256, 30_000, 384)[0] == 2
+    assert plan(256, 1_000_000, 96)[0] == 0 and plan(256, 4000, 512)[0] == 0 and plan(256, 1_000_000, 1100)[0] == 0
+    assert lib.rt_gram_plan_info(256, 0, 512, (C.c_int * 5)()) < 0
