@@ -165,7 +165,7 @@ int rt_func_lds(rt_ctx* ctx, const void* fn, int bytes) {
 
 extern "C" {
 
-int rt_version(void) { return 310; }  // 310: option gram_pace (paced / one-launch Gram); 300 (round 3): rt_dense_solve_multi, RT_P1_LOAD_P2; 210: rt_tracked_solve_batched, rt_pod_enqueue, options eig_xcd, counter gram_off_xcd
+int rt_version(void) { return 320; }  // 320: rt_gram_plan_info; 310: option gram_pace (paced / one-launch Gram); 300 (round 3): rt_dense_solve_multi, RT_P1_LOAD_P2; 210: rt_tracked_solve_batched, rt_pod_enqueue, options eig_xcd, counter gram_off_xcd
 
 int rt_ctx_create(rt_ctx** out, int device) {
   if (!out) return RT_ERR_ARG;
