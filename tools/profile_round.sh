@@ -22,6 +22,7 @@ BL="python3 $R/bench.py --steps 3 --warmup 1 --mode latency --no-cpu-baseline --
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/lat_stats -- $BL > $O/lat_stats.log 2>&1 || exit 40
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $O/lat_fetch -- $BL > $O/lat_fetch.log 2>&1 || exit 41
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $O/lat_write -- $BL > $O/lat_write.log 2>&1 || exit 42
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_VALU SQ_INSTS_MFMA --output-format csv -d $O/lat_sq -- $BL > $O/lat_sq.log 2>&1 || exit 44
 python3 $R/tools/bench_configs.py > $DEST/${ROUND}_configs_${TAG}.jsonl 2> $O/configs.log || exit 6
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/sweep_stats -- python3 $R/tools/bench_configs.py c5sweep > $O/sweep.log 2>&1 || exit 7
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/hsweep_stats -- python3 $R/tools/bench_configs.py c5h > $O/hsweep.log 2>&1 || exit 8
@@ -38,7 +39,7 @@ done
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/c4_stats -- python3 $R/tools/bench_configs.py c4 > $O/c4.log 2>&1 || exit 30
 cd $R
 python3 tools/summarize_prof.py ${ROUND}_bench_${TAG} --stats $O/stats --fetch $O/fetch --write $O/write --sq $O/sq || exit 9
-python3 tools/summarize_prof.py ${ROUND}_benchlat_${TAG} --stats $O/lat_stats --fetch $O/lat_fetch --write $O/lat_write || exit 43
+python3 tools/summarize_prof.py ${ROUND}_benchlat_${TAG} --stats $O/lat_stats --fetch $O/lat_fetch --write $O/lat_write --sq $O/lat_sq || exit 43
 KEEP=project,newton,sweep,gemm,deim,tallskinny,rank_update,skinny,gram,symeig,solve
 for W in c5sweep c5h; do
   python3 tools/summarize_prof.py ${ROUND}_${W}_${TAG} --fetch $O/${W}_fetch --write $O/${W}_write --sq $O/${W}_sq --keep $KEEP || exit 31
@@ -47,5 +48,5 @@ python3 tools/summarize_prof.py ${ROUND}_c4_${TAG} --stats $O/c4_stats --fetch $
 python3 tools/summarize_prof.py ${ROUND}_sweep_${TAG} --stats $O/sweep_stats || exit 10
 python3 tools/summarize_prof.py ${ROUND}_hsweep_${TAG} --stats $O/hsweep_stats || exit 11
 cp profiles/${ROUND}_*_${TAG}* profiles/gram_traffic.json profiles/project_traffic.json $DEST/
-rm -f $DEST/*_sweep_${TAG}_pmc.json $DEST/*_hsweep_${TAG}_pmc.json; rm -rf $O/lat_stats $O/lat_fetch $O/lat_write $O/stats $O/fetch $O/write $O/sq $O/sweep_stats $O/hsweep_stats $O/c4_stats $O/*_fetch $O/*_write $O/*_sq   # raw output is large; the summaries are what is kept
+rm -f $DEST/*_sweep_${TAG}_pmc.json $DEST/*_hsweep_${TAG}_pmc.json; rm -rf $O/lat_stats $O/lat_fetch $O/lat_write $O/lat_sq $O/stats $O/fetch $O/write $O/sq $O/sweep_stats $O/hsweep_stats $O/c4_stats $O/*_fetch $O/*_write $O/*_sq   # raw output is large; the summaries are what is kept
 ls -la $DEST
